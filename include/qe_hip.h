@@ -1,0 +1,238 @@
+/*
+ * qe_hip.h -- C ABI of libqe_hip.so: the MI355X (gfx950) drop-in for the
+ * Filter/Projection hot path of jhorstmann/queryengine.
+ *
+ * The reference has no native boundary of its own: its seam is
+ * the Kotlin operator API.  Each entry point below names the reference
+ * interface it sits beneath (paths relative to
+ * /root/reference/src/main/java/net/jhorstmann/queryengine/); INTEGRATION.md
+ * shows the Panama/JNI binding a maintainer would add on the Kotlin side.
+ *
+ * Conventions: plain C, no C++ types, no exceptions across the boundary.
+ * Every call returns int32 status (QE_OK = 0); qe_last_error(ctx) gives the
+ * message of the last failing call on that context.  The caller owns host
+ * buffers it passes in; the library owns device memory and result objects
+ * until the matching *_free.  One qe_ctx = one device + one HIP stream; a
+ * context is NOT thread-safe, distinct contexts are independent (the
+ * reference runs one thread per plan: operator/Operators.kt:5-32).
+ */
+#ifndef QE_HIP_H
+#define QE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QE_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------- */
+enum {
+    QE_OK = 0,
+    QE_ERR_INVALID_ARG = 1,   /* IllegalArgumentException analogue */
+    QE_ERR_PROGRAM = 2,       /* malformed / ill-typed expression program (TypeCheckException analogue) */
+    QE_ERR_HIP = 3,           /* HIP runtime / hiprtc failure, message carries the HIP error string */
+    QE_ERR_OOM = 4,
+    QE_ERR_UNSUPPORTED = 5,
+    QE_ERR_INTERNAL = 6,      /* includes a look-back spin that hit its bound */
+    QE_ERR_COMM = 7           /* RCCL failure */
+};
+
+/* ---- data types: data/Schema.kt:3-5 ordinals + extensions ------------------ */
+enum {
+    QE_STRING = 0,    /* int32 dictionary codes + qe_dict */
+    QE_DOUBLE = 1,    /* f64 */
+    QE_BOOLEAN = 2,   /* value bitmap: row i = word i>>6, bit i&63 (LSB first) */
+    QE_INT64 = 3,     /* extension: Java long semantics */
+    QE_INT32 = 4      /* extension: Java int semantics */
+};
+
+/* ---- expression program ----------------------------------------------------
+ * An Expression tree (ast/Expressions.kt:6-62) is serialised in POSTFIX order
+ * (operands first), little endian:
+ *
+ *   header : 'Q' 'E' 'X' <version=1>
+ *   QE_OP_COLUMN       u8 op, u8 type, u16 index          ColumnExpression(name, index, dataType) :60-62
+ *   QE_OP_NUM_LITERAL  u8 op, f64 value                   NumericLiteralExpression :17-21 (always DOUBLE)
+ *   QE_OP_BOOL_LITERAL u8 op, u8 value                    BooleanLiteralExpression :23-27
+ *   QE_OP_STR_LITERAL  u8 op, u16 nbytes, UTF-8 bytes     StringLiteralExpression :29-33
+ *   QE_OP_FUNCTION     u8 op, u8 function, u8 type        FunctionExpression :36-45; function = Function.ordinal
+ *                                                         (ast/Functions.kt:7-22), type = dataTypeNullable or 0xFF
+ *
+ * qe_expr_compile is the analogue of compileExpression (evaluator/Compiler.kt:20-26)
+ * plus the bytecode verifier pass (BytecodeCompiler.kt:138, MaxStackVisitor :177-196):
+ * it checks stack discipline, arity and operand types and infers result types.
+ */
+enum { QE_OP_COLUMN = 1, QE_OP_NUM_LITERAL = 2, QE_OP_BOOL_LITERAL = 3, QE_OP_STR_LITERAL = 4, QE_OP_FUNCTION = 16 };
+
+/* ast/Functions.kt:7-22 ordinals */
+enum {
+    QE_FN_AND = 0, QE_FN_OR, QE_FN_IF, QE_FN_NOT, QE_FN_UNARY_MINUS, QE_FN_UNARY_PLUS, QE_FN_MUL, QE_FN_DIV,
+    QE_FN_MOD, QE_FN_ADD, QE_FN_SUB, QE_FN_CMP_LT, QE_FN_CMP_LE, QE_FN_CMP_GE, QE_FN_CMP_GT, QE_FN_CMP_EQ,
+    QE_FN_CMP_NE, QE_FN_COUNT_
+};
+
+/* ast/Functions.kt:24-26 ordinals (ANY/ALL are TODO() in the reference: Accumulators.kt:16-17) */
+enum { QE_AGG_MIN = 0, QE_AGG_MAX = 1, QE_AGG_SUM = 2, QE_AGG_COUNT = 3, QE_AGG_AVG = 4 };
+
+/* ---- options ---------------------------------------------------------------- */
+enum {
+    QE_EXEC_FUSED = 0,     /* one single-pass fused kernel per plan, JIT-specialised with hiprtc
+                              (the on-device analogue of Mode.BYTECODE_COMPILER / compileProjection,
+                              BytecodeCompiler.kt:37-132) */
+    QE_EXEC_PER_NODE = 1   /* one precompiled kernel per expression node, filter first
+                              (the analogue of Mode.INTERPRETER's tree walk, Interpreter.kt:29-109) */
+};
+enum {
+    QE_CMP_TOTAL_ORDER = 0, /* java.lang.Double.compare: INTERPRETER + BYTECODE_COMPILER */
+    QE_CMP_IEEE = 1         /* primitive <,<=,>=,>: CLOSURE_COMPILER (ClosureCompiler.kt:127-130) */
+};
+
+typedef struct {
+    uint32_t struct_size;        /* = sizeof(qe_options) */
+    int32_t exec_mode;           /* QE_EXEC_* */
+    int32_t cmp_semantics;       /* QE_CMP_* */
+    int32_t profile;             /* 1: bracket the dominant kernel with HIP events (qe_ctx_kernel_time) */
+    int64_t result_capacity_rows;/* 0 = size result buffers for the worst case (every row kept) */
+    const char *jit_cache_dir;   /* NULL = $QE_JIT_CACHE_DIR or <library dir>/jit_cache */
+    int32_t tuning[8];           /* kernel tuning knobs, 0 = default; see DESIGN.md */
+} qe_options;
+
+typedef struct qe_ctx qe_ctx;
+typedef struct qe_dict qe_dict;
+typedef struct qe_batch qe_batch;
+typedef struct qe_expr qe_expr;
+typedef struct qe_result qe_result;
+
+/* ---- context ---------------------------------------------------------------- */
+/* device = QE_DEVICE_NONE gives a PLANNING-ONLY context: expressions can be
+ * compiled and verified, plans generated and JIT-compiled into the cache (hiprtc
+ * needs no GPU), but every call that would touch device memory fails with
+ * QE_ERR_HIP -- there is no CPU execution path in this library. */
+#define QE_DEVICE_NONE (-1)
+int32_t qe_abi_version(void);
+/* last error of a failed qe_ctx_create (ctx == NULL) or of ctx */
+const char *qe_last_error(const qe_ctx *ctx);
+int32_t qe_ctx_create(int32_t device, const qe_options *opts, qe_ctx **out);
+void qe_ctx_destroy(qe_ctx *ctx);
+int32_t qe_ctx_set_exec_mode(qe_ctx *ctx, int32_t exec_mode);
+int32_t qe_ctx_set_cmp_semantics(qe_ctx *ctx, int32_t cmp_semantics);
+/* HIP-event time of the dominant kernel (needs opts.profile): last launch, sum and count since reset */
+int32_t qe_ctx_kernel_time(qe_ctx *ctx, double *last_ms, double *total_ms, int64_t *launches);
+int32_t qe_ctx_reset_kernel_time(qe_ctx *ctx);
+int32_t qe_ctx_synchronize(qe_ctx *ctx);
+/* release cached device buffers back to the driver */
+int32_t qe_ctx_trim(qe_ctx *ctx);
+
+/* ---- dictionaries (STRING columns) -------------------------------------------- */
+int32_t qe_dict_create(qe_ctx *ctx, int32_t nentries, const char *const *utf8, qe_dict **out);
+int32_t qe_dict_size(const qe_dict *dict);
+const char *qe_dict_entry(const qe_dict *dict, int32_t code);
+void qe_dict_free(qe_ctx *ctx, qe_dict *dict);
+
+/* ---- batches: the columnar scan leaf --------------------------------------------
+ * Replaces MemoryTable / MemorySourceOperator (data/MemoryTable.kt:7-19,
+ * operator/MemorySourceOperator.kt:5-36) beneath Table.getScanOperator
+ * (data/Table.kt:8): columns are copied to HBM ONCE and stay resident across
+ * repeated open()/close() of the operator (T/SimpleSumBenchmark.java:63-94). */
+typedef struct {
+    int32_t type;              /* QE_* data type */
+    int32_t reserved;
+    const void *data;          /* nrows elements (BOOLEAN: ceil(nrows/64) uint64 words) */
+    const uint64_t *validity;  /* ceil(nrows/64) words, bit = 1 valid; NULL = all valid */
+    const qe_dict *dict;       /* QE_STRING only */
+} qe_col_desc;
+
+/* host buffers -> device (H2D once) */
+int32_t qe_batch_create(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out);
+/* data/validity already are device pointers owned by the caller (zero copy) */
+int32_t qe_batch_wrap_device(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out);
+
+/* schema only (types, nullability = validity != NULL, dictionaries; data ignored): for plan-time
+ * preparation (qe_filter_project_prepare / _source) without device memory */
+int32_t qe_batch_describe(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out);
+
+/* synthetic columns generated on the device from the GLOBAL row index;
+ * avoids a 24 GB H2D for the 1 B-row configurations and makes shards reproducible */
+enum { QE_GEN_I64_MOD = 0, QE_GEN_I32_MOD = 1, QE_GEN_F64_UNIT = 2, QE_GEN_F64_MOD = 3, QE_GEN_F64_STEP = 4,
+       QE_GEN_F64_PRICE = 5, QE_GEN_DICT_MOD = 6 };
+typedef struct {
+    int32_t kind;
+    int32_t col_id;       /* random stream id */
+    uint64_t modulus;
+    int64_t offset;
+    double step;
+    int32_t aux_col_id;
+    int32_t null_pct;     /* 0 = no validity bitmap */
+    const qe_dict *dict;  /* QE_GEN_DICT_MOD */
+} qe_gen_spec;
+int32_t qe_batch_generate(qe_ctx *ctx, uint64_t seed, int64_t row_begin, int64_t nrows, int32_t ncols,
+                          const qe_gen_spec *specs, qe_batch **out);
+
+int64_t qe_batch_nrows(const qe_batch *batch);
+int32_t qe_batch_ncols(const qe_batch *batch);
+int32_t qe_batch_column_type(const qe_batch *batch, int32_t col);
+/* device -> host copy of rows [row_begin, row_begin + nrows); row_begin must be a multiple of 64.
+ * validity_out may be NULL; if the column has no validity bitmap it is filled with ones */
+int32_t qe_batch_column_to_host(qe_ctx *ctx, const qe_batch *batch, int32_t col, int64_t row_begin, int64_t nrows,
+                                void *data_out, uint64_t *validity_out);
+void qe_batch_free(qe_ctx *ctx, qe_batch *batch);
+
+/* ---- expressions ------------------------------------------------------------------ */
+/* compileExpression(expression, mode): evaluator/Compiler.kt:20-26 */
+int32_t qe_expr_compile(qe_ctx *ctx, const uint8_t *program, size_t len, qe_expr **out);
+int32_t qe_expr_result_type(const qe_expr *expr);
+void qe_expr_free(qe_ctx *ctx, qe_expr *expr);
+
+/* ---- the hot path ------------------------------------------------------------------
+ * Projection(Filter(Scan)) in one call: FilterOperator.next (operator/FilterOperator.kt:14-25)
+ * + ProjectionOperator.next (operator/ProjectionOperator.kt:15-19) /
+ * CompiledProjectionOperator (BytecodeCompiler.kt:37-132) for every row of the
+ * batch, order preserving.  filter may be NULL (no Filter node).  The analogue of
+ * the Filter/Projection branches of buildPhysicalPlan (evaluator/Planner.kt:33-46). */
+int32_t qe_filter_project(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                          const qe_expr *const *projections, int32_t nproj, qe_result **out);
+/* plan-time preparation only (JIT compile + cache), no execution: what buildPhysicalPlan does */
+int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                  const qe_expr *const *projections, int32_t nproj);
+
+/* GlobalAggregation(Projection(Filter(Scan))):
+ * GlobalAggregationOperator.open (operator/GlobalAggregationOperator.kt:10-25) with
+ * Accumulators.kt:26-107 semantics: nulls skipped, empty => null, COUNT => count.
+ * SUM/AVG use a fixed-shape tree reduction (deterministic, not the reference's
+ * sequential order: see DESIGN.md for the tolerance). */
+int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                            const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg,
+                            double *out_values, uint8_t *out_valid, int64_t *out_selected_rows);
+
+/* ---- results --------------------------------------------------------------------------- */
+typedef struct {
+    int32_t type;
+    int32_t nullable;
+    const void *data;          /* DEVICE pointer: count elements (BOOLEAN: bitmap words) */
+    const uint64_t *validity;  /* DEVICE pointer or NULL */
+    int64_t count;
+    const qe_dict *dict;       /* QE_STRING: dictionary of the output codes (owned by the result) */
+} qe_col_view;
+
+int64_t qe_result_count(const qe_result *result);
+int32_t qe_result_ncols(const qe_result *result);
+int32_t qe_result_column(const qe_result *result, int32_t col, qe_col_view *out);
+/* copy one output column to host buffers sized for qe_result_count rows */
+int32_t qe_result_column_to_host(qe_ctx *ctx, const qe_result *result, int32_t col, void *data_out,
+                                 uint64_t *validity_out);
+void qe_result_free(qe_ctx *ctx, qe_result *result);
+
+/* ---- introspection ------------------------------------------------------------------------ */
+/* HIP source the JIT would compile for this plan (NUL terminated, owned by ctx, valid until next call) */
+int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                 const qe_expr *const *projections, int32_t nproj, const char **out);
+/* measured device read bandwidth of a plain streaming kernel over nbytes (GB/s): roofline calibration */
+int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, double *out_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

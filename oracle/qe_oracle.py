@@ -1,0 +1,287 @@
+"""ctypes wrapper of the CPU oracle (libqe_oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  It converts the host-side Expression tree into the oracle's own
+flat node array (NOT the product's postfix program: the two encodings are
+independent on purpose, so a bug in the product's serialiser cannot cancel out).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Any, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from queryengine_amd import ast as A
+from queryengine_amd.datatypes import DataType
+from queryengine_amd.table import Column
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+INTERPRETER, CLOSURE_COMPILER, BYTECODE_COMPILER = 0, 1, 2
+OK, THROWN, BAD_ARG = 0, 1, 2
+MIN, MAX, SUM, COUNT, AVG = 0, 1, 2, 3, 4
+
+
+class ReferenceWouldThrow(Exception):
+    """The reference evaluator would raise (ClassCastException / NPE) on this input."""
+
+
+class _Node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("fn", C.c_int32), ("dtype", C.c_int32), ("col", C.c_int32),
+                ("nops", C.c_int32), ("ops", C.c_int32 * 3), ("num", C.c_double), ("bval", C.c_int32),
+                ("pad", C.c_int32), ("str", C.c_char_p)]
+
+
+class _ValueU(C.Union):
+    _fields_ = [("d", C.c_double), ("b", C.c_int32), ("l", C.c_int64), ("i", C.c_int32), ("s", C.c_char_p)]
+
+
+class _Value(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("pad", C.c_int32), ("u", _ValueU)]
+
+
+class _Column(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("pad", C.c_int32), ("data", C.c_void_p), ("valid", C.c_void_p),
+                ("dict", C.POINTER(C.c_char_p))]
+
+
+class _OutColumn(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("pad", C.c_int32), ("data", C.c_void_p), ("valid", C.c_void_p)]
+
+
+class GenSpec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("col_id", C.c_int32), ("modulus", C.c_uint64), ("offset", C.c_int64),
+                ("step", C.c_double), ("aux_col_id", C.c_int32), ("null_pct", C.c_int32)]
+
+
+_lib = None
+
+
+def build() -> str:
+    path = os.path.join(_HERE, "libqe_oracle.so")
+    subprocess.run(["make", "-s", "-C", _HERE, "libqe_oracle.so"], check=True)
+    return path
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libqe_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.qo_eval.restype = C.c_int32
+        L.qo_eval.argtypes = [C.POINTER(_Node), C.c_int32, C.POINTER(_Value), C.c_int32, C.POINTER(_Value)]
+        L.qo_filter_project.restype = C.c_int64
+        L.qo_filter_project.argtypes = [C.POINTER(_Node), C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                        C.POINTER(_Column), C.c_int32, C.c_int64, C.c_int32,
+                                        C.POINTER(_OutColumn), C.POINTER(C.c_int32)]
+        L.qo_filter_aggregate.restype = C.c_int64
+        L.qo_filter_aggregate.argtypes = [C.POINTER(_Node), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                          C.c_int32, C.POINTER(_Column), C.c_int32, C.c_int64, C.c_int32,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+        L.qo_generate.restype = None
+        L.qo_generate.argtypes = [C.POINTER(GenSpec), C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.qo_gen_raw.restype = C.c_uint64
+        L.qo_gen_raw.argtypes = [C.c_uint64, C.c_int32, C.c_uint64]
+        L.qo_double_compare.restype = C.c_int32
+        L.qo_double_compare.argtypes = [C.c_double, C.c_double]
+        L.qo_double_equals.restype = C.c_int32
+        L.qo_double_equals.argtypes = [C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+class _TreeBuilder(A.ExpressionVisitor):
+    """Expression tree -> flat qo_node list; returns the node index."""
+
+    def __init__(self):
+        self.nodes: List[_Node] = []
+        self.keep: List[Any] = []
+
+    def _add(self, n: _Node) -> int:
+        self.nodes.append(n)
+        return len(self.nodes) - 1
+
+    def visitIdentifier(self, expr):
+        raise RuntimeError("Identifier not expected during evaluation")   # Interpreter.kt:9-11
+
+    def visitNumericLiteral(self, expr):
+        n = _Node(); n.kind = 1; n.dtype = int(DataType.DOUBLE); n.num = float(expr.value)
+        return self._add(n)
+
+    def visitBooleanLiteral(self, expr):
+        n = _Node(); n.kind = 2; n.dtype = int(DataType.BOOLEAN); n.bval = 1 if expr.value else 0
+        return self._add(n)
+
+    def visitStringLiteral(self, expr):
+        n = _Node(); n.kind = 3; n.dtype = int(DataType.STRING)
+        b = expr.value.encode("utf-8"); self.keep.append(b); n.str = b
+        return self._add(n)
+
+    def visitColumn(self, expr):
+        n = _Node(); n.kind = 0; n.dtype = int(expr.dataType); n.col = expr.index
+        return self._add(n)
+
+    def visitFunction(self, expr):
+        ops = [op.accept(self) for op in expr.operands]
+        n = _Node(); n.kind = 4; n.fn = expr.function.ordinal
+        n.dtype = int(expr.dataTypeNullable) if expr.dataTypeNullable is not None else -1
+        n.nops = len(ops)
+        for i, o in enumerate(ops):
+            n.ops[i] = o
+        return self._add(n)
+
+    def visitAggregationFunction(self, expr):
+        raise RuntimeError("Unexpected aggregation expression in expression compiler")
+
+    def array(self):
+        arr = (_Node * max(1, len(self.nodes)))()
+        for i, n in enumerate(self.nodes):
+            arr[i] = n
+        return arr
+
+
+def _box(v: Any, keep: list) -> _Value:
+    out = _Value()
+    if v is None:
+        out.tag = 0
+    elif isinstance(v, bool):
+        out.tag = 2; out.u.b = 1 if v else 0
+    elif isinstance(v, float):
+        out.tag = 1; out.u.d = v
+    elif isinstance(v, str):
+        b = v.encode("utf-8"); keep.append(b)
+        out.tag = 3; out.u.s = b
+    elif isinstance(v, np.int32):
+        out.tag = 5; out.u.i = int(v)
+    elif isinstance(v, (int, np.int64)):
+        out.tag = 4; out.u.l = int(v)
+    else:
+        raise TypeError(type(v))
+    return out
+
+
+def _unbox(v: _Value) -> Any:
+    if v.tag == 0: return None
+    if v.tag == 1: return float(v.u.d)
+    if v.tag == 2: return bool(v.u.b)
+    if v.tag == 3: return v.u.s.decode("utf-8")
+    if v.tag == 4: return int(v.u.l)
+    if v.tag == 5: return int(v.u.i)
+    raise ValueError(v.tag)
+
+
+def eval_row(expr: A.Expression, row: Sequence[Any], mode: int = INTERPRETER) -> Any:
+    """``compileExpression(expr, mode)(row)`` -- boxed Python values, ``int`` = INT64, ``np.int32`` = INT32."""
+    tb = _TreeBuilder()
+    root = expr.accept(tb)
+    keep: list = []
+    vals = (_Value * max(1, len(row)))()
+    for i, v in enumerate(row):
+        vals[i] = _box(v, keep)
+    out = _Value()
+    st = lib().qo_eval(tb.array(), root, vals, mode, C.byref(out))
+    if st == THROWN:
+        raise ReferenceWouldThrow()
+    if st != OK:
+        raise ValueError(f"oracle status {st}")
+    return _unbox(out)
+
+
+def _columns(cols: Sequence[Column], keep: list):
+    arr = (_Column * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i].dtype = int(c.type)
+        data = c.data.astype(np.uint8) if c.type == DataType.BOOLEAN else c.data
+        data = np.ascontiguousarray(data)
+        keep.append(data)
+        arr[i].data = data.ctypes.data
+        if c.valid is not None:
+            v = np.ascontiguousarray(c.valid.astype(np.uint8)); keep.append(v)
+            arr[i].valid = v.ctypes.data
+        else:
+            arr[i].valid = None
+        if c.type == DataType.STRING:
+            enc = [s.encode("utf-8") for s in c.dictionary]
+            d = (C.c_char_p * max(1, len(enc)))(*enc)
+            keep.extend([enc, d])
+            arr[i].dict = d
+    return arr
+
+
+_OUT_NP = {DataType.DOUBLE: np.float64, DataType.INT64: np.int64, DataType.INT32: np.int32,
+           DataType.BOOLEAN: np.uint8, DataType.STRING: np.uintp}
+
+
+def filter_project(cols: Sequence[Column], filter_expr: Optional[A.Expression],
+                   projections: Sequence[A.Expression], mode: int = INTERPRETER) -> List[Column]:
+    """Projection(Filter(Scan)) through the row-at-a-time oracle; returns output columns.
+
+    STRING outputs come back with their own dictionary (order of first appearance)."""
+    nrows = len(cols[0]) if cols else 0
+    tb = _TreeBuilder()
+    froot = filter_expr.accept(tb) if filter_expr is not None else -1
+    proots = [p.accept(tb) for p in projections]
+    keep: list = []
+    carr = _columns(cols, keep)
+    outs = (_OutColumn * max(1, len(projections)))()
+    bufs: List[Tuple[np.ndarray, np.ndarray]] = []
+    for k, p in enumerate(projections):
+        t = p.dataType
+        data = np.zeros(max(1, nrows), dtype=_OUT_NP[t]); valid = np.zeros(max(1, nrows), dtype=np.uint8)
+        bufs.append((data, valid))
+        outs[k].dtype = int(t); outs[k].data = data.ctypes.data; outs[k].valid = valid.ctypes.data
+    err = C.c_int32(0)
+    proots_arr = (C.c_int32 * max(1, len(proots)))(*proots)
+    n = lib().qo_filter_project(tb.array(), froot, proots_arr, len(proots), carr, len(cols), nrows, mode,
+                                outs, C.byref(err))
+    if n < 0:
+        if err.value == THROWN:
+            raise ReferenceWouldThrow()
+        raise ValueError(f"oracle status {err.value}")
+    result = []
+    for (data, valid), p in zip(bufs, projections):
+        t = p.dataType
+        v = valid[:n].astype(np.bool_)
+        if t == DataType.STRING:
+            strs = [C.cast(int(ptr), C.c_char_p).value.decode("utf-8") if ok else None
+                    for ptr, ok in zip(data[:n], v)]
+            result.append(Column.from_values(DataType.STRING, strs))
+        elif t == DataType.BOOLEAN:
+            result.append(Column(t, data[:n].astype(np.bool_), v))
+        else:
+            result.append(Column(t, data[:n].copy(), v))
+    return result
+
+
+def filter_aggregate(cols: Sequence[Column], filter_expr: Optional[A.Expression],
+                     exprs: Sequence[A.Expression], aggs: Sequence[int], mode: int = INTERPRETER):
+    """GlobalAggregation(Projection(Filter(Scan))): returns (list of float|None, selected row count)."""
+    nrows = len(cols[0]) if cols else 0
+    tb = _TreeBuilder()
+    froot = filter_expr.accept(tb) if filter_expr is not None else -1
+    roots = [e.accept(tb) for e in exprs]
+    keep: list = []
+    carr = _columns(cols, keep)
+    vals = (C.c_double * max(1, len(exprs)))(); valid = (C.c_uint8 * max(1, len(exprs)))()
+    err = C.c_int32(0)
+    n = lib().qo_filter_aggregate(tb.array(), froot, (C.c_int32 * max(1, len(roots)))(*roots),
+                                  (C.c_int32 * max(1, len(aggs)))(*[int(a) for a in aggs]), len(exprs),
+                                  carr, len(cols), nrows, mode, vals, valid, C.byref(err))
+    if n < 0:
+        if err.value == THROWN:
+            raise ReferenceWouldThrow()
+        raise ValueError(f"oracle status {err.value}")
+    return [float(vals[i]) if valid[i] else None for i in range(len(exprs))], int(n)
+
+
+def generate(spec: GenSpec, seed: int, row_begin: int, nrows: int, np_dtype) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    data = np.zeros(nrows, dtype=np_dtype)
+    valid = np.zeros(nrows, dtype=np.uint8) if spec.null_pct > 0 else None
+    lib().qo_generate(C.byref(spec), seed, row_begin, nrows, data.ctypes.data,
+                      valid.ctypes.data if valid is not None else None)
+    return data, (valid.astype(np.bool_) if valid is not None else None)

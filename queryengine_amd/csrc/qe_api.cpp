@@ -1,0 +1,810 @@
+// qe_api.cpp -- the C ABI of libqe_hip.so (include/qe_hip.h): contexts, HBM-resident
+// batches, expression handles, the fused filter+project / filter+aggregate calls, results.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <sstream>
+
+#include "qe_internal.h"
+#include "qe_kernels.h"
+#include "qe_pernode.h"
+
+namespace qe {
+
+void fail(int32_t code, const std::string &msg) { throw Error{code, msg}; }
+
+void hip_check(hipError_t e, const char *what, const char *file, int line) {
+    if (e == hipSuccess) return;
+    std::ostringstream s;
+    s << what << " failed: " << hipGetErrorString(e) << " (" << (int)e << ") at " << file << ":" << line;
+    fail(e == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_HIP, s.str());
+}
+
+// ---- pool ------------------------------------------------------------------------------
+void *Pool::alloc(size_t bytes) {
+    bytes = std::max<size_t>(256, (bytes + 255) & ~size_t(255));
+    auto it = free_.lower_bound(bytes);
+    if (it != free_.end() && it->first <= bytes + bytes / 4) {
+        void *p = it->second;
+        bytes_cached -= it->first;
+        bytes_in_use += it->first;
+        live_[p] = it->first;
+        free_.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory && !free_.empty()) {
+        (void)hipGetLastError();
+        trim_all();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(QE_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    }
+    live_[p] = bytes;
+    bytes_in_use += bytes;
+    return p;
+}
+
+void Pool::release(void *p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    bytes_in_use -= it->second;
+    bytes_cached += it->second;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+
+void Pool::trim_all() {
+    for (auto &kv : free_) (void)hipFree(kv.second);
+    free_.clear();
+    bytes_cached = 0;
+}
+void Pool::trim() { trim_all(); }
+
+}  // namespace qe
+
+using namespace qe;
+
+static thread_local std::string g_create_error;
+
+template <typename F>
+static int32_t guarded(qe_ctx *ctx, F &&f) {
+    try {
+        f();
+        return QE_OK;
+    } catch (const Error &e) {
+        (ctx ? ctx->last_error : g_create_error) = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        (ctx ? ctx->last_error : g_create_error) = "host out of memory";
+        return QE_ERR_OOM;
+    } catch (const std::exception &e) {
+        (ctx ? ctx->last_error : g_create_error) = e.what();
+        return QE_ERR_INTERNAL;
+    }
+}
+
+static void need_device(const qe_ctx *ctx) {
+    if (ctx->device < 0)
+        fail(QE_ERR_HIP, "planning-only context (QE_DEVICE_NONE): this call needs a HIP device; libqe_hip has no CPU fallback");
+    QE_HIP(hipSetDevice(ctx->device));
+}
+
+static size_t type_width(int t) {
+    switch (t) {
+    case QE_DOUBLE: case QE_INT64: return 8;
+    case QE_INT32: case QE_STRING: return 4;
+    default: return 0;
+    }
+}
+static size_t column_bytes(int t, int64_t n) {
+    return t == QE_BOOLEAN ? (size_t)((n + 63) / 64) * 8 : type_width(t) * (size_t)n;
+}
+static size_t bitmap_bytes(int64_t n) { return (size_t)((n + 63) / 64) * 8; }
+
+static std::string default_cache_dir() {
+    if (const char *e = std::getenv("QE_JIT_CACHE_DIR")) return e;
+    Dl_info info;
+    if (dladdr((void *)&default_cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s) + "/jit_cache";
+    }
+    return "jit_cache";
+}
+
+extern "C" {
+
+int32_t qe_abi_version(void) { return QE_ABI_VERSION; }
+
+const char *qe_last_error(const qe_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int32_t qe_ctx_create(int32_t device, const qe_options *opts, qe_ctx **out) {
+    if (!out) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    qe_ctx *ctx = nullptr;
+    int32_t st = guarded(nullptr, [&] {
+        if (device == QE_DEVICE_NONE) {   // planning-only context: no HIP call at all
+            ctx = new qe_ctx();
+            ctx->device = device;
+            if (opts) std::memcpy(&ctx->opts, opts, std::min<size_t>(opts->struct_size, sizeof(qe_options)));
+            ctx->opts.struct_size = sizeof(qe_options);
+            ctx->jit.reset(new Jit(ctx->opts.jit_cache_dir ? ctx->opts.jit_cache_dir : default_cache_dir()));
+            ctx->opts.jit_cache_dir = nullptr;
+            return;
+        }
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) {
+            (void)hipGetLastError();
+            fail(QE_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e) +
+                                 " (libqe_hip has no CPU fallback)");
+        }
+        if (device < 0 || device >= ndev) fail(QE_ERR_INVALID_ARG, "device ordinal out of range");
+        ctx = new qe_ctx();
+        ctx->device = device;
+        if (opts) {
+            size_t n = std::min<size_t>(opts->struct_size, sizeof(qe_options));
+            std::memcpy(&ctx->opts, opts, n);
+        }
+        ctx->opts.struct_size = sizeof(qe_options);
+        QE_HIP(hipSetDevice(device));
+        QE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        QE_HIP(hipEventCreate(&ctx->ev0));
+        QE_HIP(hipEventCreate(&ctx->ev1));
+        QE_HIP(hipMalloc((void **)&ctx->d_ctrl, 256));
+        QE_HIP(hipHostMalloc((void **)&ctx->h_ctrl, 256, hipHostMallocDefault));
+        ctx->jit.reset(new Jit(ctx->opts.jit_cache_dir ? ctx->opts.jit_cache_dir : default_cache_dir()));
+        ctx->opts.jit_cache_dir = nullptr;
+    });
+    if (st != QE_OK) {
+        delete ctx;
+        return st;
+    }
+    *out = ctx;
+    return QE_OK;
+}
+
+void qe_ctx_destroy(qe_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->device < 0) {
+        delete ctx;
+        return;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->plans.clear();
+    ctx->jit.reset();
+    ctx->pool.trim();
+    if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
+    if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t qe_ctx_set_exec_mode(qe_ctx *ctx, int32_t m) {
+    if (!ctx || (m != QE_EXEC_FUSED && m != QE_EXEC_PER_NODE)) return QE_ERR_INVALID_ARG;
+    ctx->opts.exec_mode = m;
+    return QE_OK;
+}
+int32_t qe_ctx_set_cmp_semantics(qe_ctx *ctx, int32_t m) {
+    if (!ctx || (m != QE_CMP_TOTAL_ORDER && m != QE_CMP_IEEE)) return QE_ERR_INVALID_ARG;
+    ctx->opts.cmp_semantics = m;
+    return QE_OK;
+}
+int32_t qe_ctx_kernel_time(qe_ctx *ctx, double *last_ms, double *total_ms, int64_t *launches) {
+    if (!ctx) return QE_ERR_INVALID_ARG;
+    if (last_ms) *last_ms = ctx->last_ms;
+    if (total_ms) *total_ms = ctx->total_ms;
+    if (launches) *launches = ctx->launches;
+    return QE_OK;
+}
+int32_t qe_ctx_reset_kernel_time(qe_ctx *ctx) {
+    if (!ctx) return QE_ERR_INVALID_ARG;
+    ctx->last_ms = ctx->total_ms = 0.0;
+    ctx->launches = 0;
+    return QE_OK;
+}
+int32_t qe_ctx_synchronize(qe_ctx *ctx) {
+    if (!ctx) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] { need_device(ctx); QE_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+int32_t qe_ctx_trim(qe_ctx *ctx) {
+    if (!ctx) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->pool.trim();
+    });
+}
+
+// ---- dictionaries ---------------------------------------------------------------------------
+int32_t qe_dict_create(qe_ctx *ctx, int32_t nentries, const char *const *utf8, qe_dict **out) {
+    if (!ctx || !out || nentries < 0 || (nentries > 0 && !utf8)) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        auto d = std::make_shared<DictData>();
+        d->entries.reserve(nentries);
+        for (int32_t i = 0; i < nentries; i++) {
+            if (!utf8[i]) fail(QE_ERR_INVALID_ARG, "null dictionary entry");
+            d->entries.emplace_back(utf8[i]);
+            d->index.emplace(d->entries.back(), i);   // first occurrence wins
+        }
+        *out = new qe_dict{d};
+    });
+}
+int32_t qe_dict_size(const qe_dict *dict) { return dict && dict->d ? (int32_t)dict->d->entries.size() : 0; }
+const char *qe_dict_entry(const qe_dict *dict, int32_t code) {
+    if (!dict || !dict->d || code < 0 || code >= (int32_t)dict->d->entries.size()) return nullptr;
+    return dict->d->entries[code].c_str();
+}
+void qe_dict_free(qe_ctx *, qe_dict *dict) { delete dict; }
+
+// ---- batches ------------------------------------------------------------------------------------
+static void free_batch(qe_ctx *ctx, qe_batch *b) {
+    if (!b) return;
+    for (auto &c : b->cols)
+        if (c.owned) {
+            ctx->pool.release(c.data);
+            ctx->pool.release(c.validity);
+        }
+    delete b;
+}
+
+static void check_col_desc(const qe_col_desc &d, int64_t nrows) {
+    if (d.type < QE_STRING || d.type > QE_INT32) fail(QE_ERR_INVALID_ARG, "bad column type");
+    if (nrows > 0 && !d.data) fail(QE_ERR_INVALID_ARG, "null column data");
+    if (d.type == QE_STRING && (!d.dict || !d.dict->d)) fail(QE_ERR_INVALID_ARG, "STRING column needs a dictionary");
+}
+
+int32_t qe_batch_create(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out) {
+    if (!ctx || !out || nrows < 0 || ncols < 0 || (ncols > 0 && !cols)) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    qe_batch *b = nullptr;
+    int32_t st = guarded(ctx, [&] {
+        need_device(ctx);
+        b = new qe_batch();
+        b->nrows = nrows;
+        for (int32_t j = 0; j < ncols; j++) {
+            check_col_desc(cols[j], nrows);
+            Column c;
+            c.type = cols[j].type;
+            if (c.type == QE_STRING) c.dict = cols[j].dict->d;
+            size_t nb = column_bytes(c.type, nrows);
+            c.data = ctx->pool.alloc(std::max<size_t>(nb, 16));
+            b->cols.push_back(c);
+            if (nb) QE_HIP(hipMemcpyAsync(c.data, cols[j].data, nb, hipMemcpyHostToDevice, ctx->stream));
+            if (cols[j].validity && nrows > 0) {
+                b->cols.back().validity = (uint64_t *)ctx->pool.alloc(bitmap_bytes(nrows));
+                QE_HIP(hipMemcpyAsync(b->cols.back().validity, cols[j].validity, bitmap_bytes(nrows),
+                                      hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        QE_HIP(hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
+    });
+    if (st != QE_OK) {
+        free_batch(ctx, b);
+        return st;
+    }
+    *out = b;
+    return QE_OK;
+}
+
+int32_t qe_batch_wrap_device(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out) {
+    if (!ctx || !out || nrows < 0 || ncols < 0 || (ncols > 0 && !cols)) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    qe_batch *b = nullptr;
+    int32_t st = guarded(ctx, [&] {
+        b = new qe_batch();
+        b->nrows = nrows;
+        for (int32_t j = 0; j < ncols; j++) {
+            check_col_desc(cols[j], nrows);
+            if (((uintptr_t)cols[j].data & 15) || ((uintptr_t)cols[j].validity & 7))
+                fail(QE_ERR_INVALID_ARG, "device column pointers must be 16-byte aligned (validity: 8)");
+            Column c;
+            c.type = cols[j].type;
+            c.data = const_cast<void *>(cols[j].data);
+            c.validity = const_cast<uint64_t *>(cols[j].validity);
+            if (c.type == QE_STRING) c.dict = cols[j].dict->d;
+            c.owned = false;
+            b->cols.push_back(c);
+        }
+    });
+    if (st != QE_OK) {
+        delete b;
+        return st;
+    }
+    *out = b;
+    return QE_OK;
+}
+
+int32_t qe_batch_describe(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_col_desc *cols, qe_batch **out) {
+    if (!ctx || !out || nrows < 0 || ncols < 0 || (ncols > 0 && !cols)) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    qe_batch *b = nullptr;
+    int32_t st = guarded(ctx, [&] {
+        b = new qe_batch();
+        b->nrows = nrows;
+        b->schema_only = true;
+        for (int32_t j = 0; j < ncols; j++) {
+            if (cols[j].type < QE_STRING || cols[j].type > QE_INT32) fail(QE_ERR_INVALID_ARG, "bad column type");
+            if (cols[j].type == QE_STRING && (!cols[j].dict || !cols[j].dict->d))
+                fail(QE_ERR_INVALID_ARG, "STRING column needs a dictionary");
+            Column c;
+            c.type = cols[j].type;
+            c.validity = cols[j].validity ? (uint64_t *)(uintptr_t)8 : nullptr;   // nullability marker only
+            if (c.type == QE_STRING) c.dict = cols[j].dict->d;
+            c.owned = false;
+            b->cols.push_back(c);
+        }
+    });
+    if (st != QE_OK) {
+        delete b;
+        return st;
+    }
+    *out = b;
+    return QE_OK;
+}
+
+int32_t qe_batch_generate(qe_ctx *ctx, uint64_t seed, int64_t row_begin, int64_t nrows, int32_t ncols,
+                          const qe_gen_spec *specs, qe_batch **out) {
+    if (!ctx || !out || nrows < 0 || row_begin < 0 || ncols < 0 || (ncols > 0 && !specs)) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    qe_batch *b = nullptr;
+    int32_t st = guarded(ctx, [&] {
+        need_device(ctx);
+        b = new qe_batch();
+        b->nrows = nrows;
+        for (int32_t j = 0; j < ncols; j++) {
+            const qe_gen_spec &g = specs[j];
+            Column c;
+            switch (g.kind) {
+            case QE_GEN_I64_MOD: c.type = QE_INT64; break;
+            case QE_GEN_I32_MOD: c.type = QE_INT32; break;
+            case QE_GEN_DICT_MOD:
+                c.type = QE_STRING;
+                if (!g.dict || !g.dict->d) fail(QE_ERR_INVALID_ARG, "QE_GEN_DICT_MOD needs a dictionary");
+                if (g.modulus > g.dict->d->entries.size() || g.offset != 0)
+                    fail(QE_ERR_INVALID_ARG, "QE_GEN_DICT_MOD codes exceed the dictionary");
+                c.dict = g.dict->d;
+                break;
+            case QE_GEN_F64_UNIT: case QE_GEN_F64_MOD: case QE_GEN_F64_STEP: case QE_GEN_F64_PRICE: c.type = QE_DOUBLE; break;
+            default: fail(QE_ERR_INVALID_ARG, "bad generator kind");
+            }
+            if (g.kind != QE_GEN_F64_UNIT && g.kind != QE_GEN_F64_PRICE && g.modulus == 0)
+                fail(QE_ERR_INVALID_ARG, "generator modulus must be > 0");
+            c.data = ctx->pool.alloc(std::max<size_t>(column_bytes(c.type, nrows), 16));
+            if (g.null_pct > 0 && nrows > 0) c.validity = (uint64_t *)ctx->pool.alloc(bitmap_bytes(nrows));
+            b->cols.push_back(c);
+            launch_generate(ctx->stream, g, seed, row_begin, nrows, c.data, c.validity);
+        }
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+    });
+    if (st != QE_OK) {
+        free_batch(ctx, b);
+        return st;
+    }
+    *out = b;
+    return QE_OK;
+}
+
+int64_t qe_batch_nrows(const qe_batch *b) { return b ? b->nrows : -1; }
+int32_t qe_batch_ncols(const qe_batch *b) { return b ? (int32_t)b->cols.size() : -1; }
+int32_t qe_batch_column_type(const qe_batch *b, int32_t col) {
+    return (b && col >= 0 && col < (int32_t)b->cols.size()) ? b->cols[col].type : -1;
+}
+
+int32_t qe_batch_column_to_host(qe_ctx *ctx, const qe_batch *b, int32_t col, int64_t row_begin, int64_t nrows,
+                                void *data_out, uint64_t *validity_out) {
+    if (!ctx || !b || col < 0 || col >= (int32_t)b->cols.size() || row_begin < 0 || nrows < 0 ||
+        row_begin + nrows > b->nrows || (row_begin & 63))
+        return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        const Column &c = b->cols[col];
+        if (nrows == 0) return;
+        if (data_out) {
+            if (c.type == QE_BOOLEAN)
+                QE_HIP(hipMemcpyAsync(data_out, (const char *)c.data + (row_begin / 64) * 8, bitmap_bytes(nrows),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+            else
+                QE_HIP(hipMemcpyAsync(data_out, (const char *)c.data + type_width(c.type) * (size_t)row_begin,
+                                      type_width(c.type) * (size_t)nrows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (validity_out) {
+            if (c.validity)
+                QE_HIP(hipMemcpyAsync(validity_out, c.validity + row_begin / 64, bitmap_bytes(nrows),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+            else
+                std::memset(validity_out, 0xff, bitmap_bytes(nrows));
+        }
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void qe_batch_free(qe_ctx *ctx, qe_batch *b) {
+    if (!ctx) return;
+    free_batch(ctx, b);
+}
+
+// ---- expressions ---------------------------------------------------------------------------------
+int32_t qe_expr_compile(qe_ctx *ctx, const uint8_t *program, size_t len, qe_expr **out) {
+    if (!ctx || !out) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        Expr e = decode_program(program, len);
+        *out = new qe_expr{std::move(e)};
+    });
+}
+int32_t qe_expr_result_type(const qe_expr *e) { return e ? e->e.nodes[e->e.root].type : -1; }
+void qe_expr_free(qe_ctx *, qe_expr *e) { delete e; }
+
+}  // extern "C"
+
+// ---- plans --------------------------------------------------------------------------------------------
+namespace {
+
+FusedGeometry geometry_of(const qe_ctx *ctx) {
+    FusedGeometry g;
+    const int t = ctx->opts.tuning[0], u = ctx->opts.tuning[1];
+    if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) g.threads = t;
+    if (u >= 1 && u <= 16) g.unroll = u;
+    return g;
+}
+
+std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                               const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load) {
+    if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
+    CodegenInput in;
+    in.filter = filter ? &filter->e : nullptr;
+    for (int32_t i = 0; i < nproj; i++) {
+        if (!projs[i]) fail(QE_ERR_INVALID_ARG, "null projection");
+        in.projections.push_back(&projs[i]->e);
+        if (agg_fns) {
+            if (agg_fns[i] < QE_AGG_MIN || agg_fns[i] > QE_AGG_AVG) fail(QE_ERR_UNSUPPORTED, "unsupported aggregation function");
+            in.agg_fns.push_back(agg_fns[i]);
+        }
+    }
+    in.cmp_semantics = ctx->opts.cmp_semantics;
+    in.geo = geometry_of(ctx);
+    in.nontemporal = ctx->opts.tuning[2] == 2 ? 0 : 1;
+    std::ostringstream key;
+    key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "n"
+        << in.nontemporal << "|";
+    for (const Column &c : batch->cols) {
+        in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
+        key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
+    }
+    auto add_prog = [&](const Expr *e) {
+        key << "|";
+        if (e) key.write((const char *)e->program.data(), (std::streamsize)e->program.size());
+    };
+    add_prog(in.filter);
+    for (const Expr *e : in.projections) add_prog(e);
+    if (agg_fns)
+        for (int a : in.agg_fns) key << "|a" << a;
+    const std::string k = key.str();
+    auto it = ctx->plans.find(k);
+    if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
+    auto plan = std::make_shared<Plan>();
+    plan->cg = generate_fused_source(in);
+    plan->geo = in.geo;
+    plan->aggregate = agg_fns != nullptr;
+    plan->kernel = ctx->jit->get(plan->cg.source, "qe_fused", load);
+    ctx->plans[k] = plan;
+    return plan;
+}
+
+int device_cus(int device) {
+    int cus = 0;
+    QE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    return cus > 0 ? cus : 256;
+}
+
+int blocks_per_cu(const qe_ctx *ctx, const Plan &plan) {
+    if (ctx->opts.tuning[3] > 0) return ctx->opts.tuning[3];
+    int nb = 0;
+    hipError_t e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, plan.kernel.fn, plan.geo.threads, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 2;
+    }
+    return std::max(1, std::min(nb, 8));
+}
+
+void fill_inputs(FusedParams &p, const qe_batch *batch, const Plan &plan) {
+    std::memset(&p, 0, sizeof p);
+    for (size_t s = 0; s < plan.cg.used_cols.size(); s++) {
+        const Column &c = batch->cols[plan.cg.used_cols[s]];
+        p.col[s] = c.data;
+        p.colvalid[s] = (const unsigned long long *)c.validity;
+    }
+    p.nrows = batch->nrows;
+}
+
+void launch_fused(qe_ctx *ctx, const Plan &plan, FusedParams &p, int grid) {
+    void *args[] = {&p};
+    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    QE_HIP(hipModuleLaunchKernel(plan.kernel.fn, grid, 1, 1, plan.geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+}
+
+void collect_time(qe_ctx *ctx) {
+    if (!ctx->opts.profile) return;
+    float ms = 0.f;
+    QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->last_ms = ms;
+    ctx->total_ms += ms;
+    ctx->launches++;
+}
+
+void free_result(qe_ctx *ctx, qe_result *r) {
+    if (!r) return;
+    for (auto &c : r->cols) {
+        ctx->pool.release(c.data);
+        ctx->pool.release(c.validity);
+        ctx->pool.release(c.bytes_data);
+        ctx->pool.release(c.bytes_valid);
+    }
+    delete r;
+}
+
+qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projs,
+                     int32_t nproj) {
+    auto plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true);
+    const int64_t n = batch->nrows;
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(),
+                                                                      [ctx](qe_result *r) { free_result(ctx, r); });
+    int64_t cap = ctx->opts.result_capacity_rows > 0 ? std::min<int64_t>(ctx->opts.result_capacity_rows, n) : n;
+    res->capacity = cap;
+    for (const OutSpec &os : plan->cg.outs) {
+        OutColumn oc;
+        oc.type = os.type;
+        oc.nullable = os.nullable;
+        oc.dict = os.dict;
+        oc.dict_handle.d = os.dict;
+        res->cols.push_back(oc);
+    }
+    if (n == 0) return res.release();
+    FusedParams p;
+    fill_inputs(p, batch, *plan);
+    for (size_t i = 0; i < res->cols.size(); i++) {
+        OutColumn &oc = res->cols[i];
+        if (oc.type == QE_BOOLEAN) {
+            oc.bytes_data = ctx->pool.alloc((size_t)std::max<int64_t>(cap, 1));
+            p.out[i] = oc.bytes_data;
+        } else {
+            oc.data = ctx->pool.alloc(std::max<size_t>(type_width(oc.type) * (size_t)cap, 16));
+            p.out[i] = oc.data;
+        }
+        if (oc.nullable) {
+            oc.bytes_valid = (uint8_t *)ctx->pool.alloc((size_t)std::max<int64_t>(cap, 1));
+            p.outvalid[i] = oc.bytes_valid;
+        }
+    }
+    const int64_t tile_rows = plan->geo.tile_rows();
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    if (ntiles >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit tile tickets");
+    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc((size_t)ntiles * 8);
+    struct DescGuard {
+        qe_ctx *c; void *p;
+        ~DescGuard() { c->pool.release(p); }
+    } dg{ctx, desc};
+    p.capacity = cap;
+    p.desc = desc;
+    p.ticket = ctx->d_ctrl;
+    p.error = ctx->d_ctrl + 1;
+    p.total = (unsigned long long *)(ctx->d_ctrl + 2);
+    p.ntiles = ntiles;
+    // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
+    QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));
+    QE_HIP(hipMemsetAsync(desc, 0, (size_t)ntiles * 8, ctx->stream));
+    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan));
+    launch_fused(ctx, *plan, p, grid);
+    QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    collect_time(ctx);
+    const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+    if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
+    const unsigned long long total = ctx->h_ctrl[1];
+    if ((int64_t)total > cap)
+        fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(total) + " rows but result_capacity_rows is " +
+                                     std::to_string(cap));
+    res->count = (int64_t)total;
+    // nullable / boolean outputs were written one byte per row: pack them into bitmaps
+    bool packed = false;
+    for (OutColumn &oc : res->cols) {
+        if (oc.type == QE_BOOLEAN) {
+            oc.data = ctx->pool.alloc(std::max<size_t>(bitmap_bytes(res->count), 16));
+            launch_pack_bytes(ctx->stream, (const uint8_t *)oc.bytes_data, res->count, (uint64_t *)oc.data);
+            packed = true;
+        }
+        if (oc.nullable) {
+            oc.validity = (uint64_t *)ctx->pool.alloc(std::max<size_t>(bitmap_bytes(res->count), 16));
+            launch_pack_bytes(ctx->stream, oc.bytes_valid, res->count, oc.validity);
+            packed = true;
+        }
+    }
+    if (packed) {
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        for (OutColumn &oc : res->cols) {
+            ctx->pool.release(oc.bytes_data);
+            ctx->pool.release(oc.bytes_valid);
+            oc.bytes_data = nullptr;
+            oc.bytes_valid = nullptr;
+        }
+    }
+    return res.release();
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t qe_filter_project(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                          const qe_expr *const *projections, int32_t nproj, qe_result **out) {
+    if (!ctx || !batch || !out) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
+        if (ctx->opts.exec_mode == QE_EXEC_PER_NODE)
+            *out = run_per_node(ctx, batch, filter, projections, nproj);
+        else
+            *out = run_fused(ctx, batch, filter, projections, nproj);
+    });
+}
+
+int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                  const qe_expr *const *projections, int32_t nproj) {
+    if (!ctx || !batch) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        if (ctx->device >= 0) need_device(ctx);
+        if (ctx->opts.exec_mode == QE_EXEC_FUSED)
+            (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0);
+    });
+}
+
+int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                 const qe_expr *const *projections, int32_t nproj, const char **out) {
+    if (!ctx || !batch || !out) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false);
+        ctx->source_scratch = plan->cg.source;
+        *out = ctx->source_scratch.c_str();
+    });
+}
+
+int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *exprs,
+                            const int32_t *agg_fns, int32_t nagg, double *out_values, uint8_t *out_valid,
+                            int64_t *out_selected_rows) {
+    if (!ctx || !batch || nagg <= 0 || !exprs || !agg_fns || !out_values || !out_valid) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
+        auto plan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true);
+        const int64_t n = batch->nrows;
+        const int64_t tile_rows = plan->geo.tile_rows();
+        const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+        // fixed grid => fixed reduction tree => bitwise reproducible sums on a given device
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(ctx->device) * 4));
+        const int stride = 2 * nagg + 1;
+        std::vector<double> partial((size_t)grid * stride, 0.0);
+        if (ntiles > 0) {
+            FusedParams p;
+            fill_inputs(p, batch, *plan);
+            double *d_partial = (double *)ctx->pool.alloc(partial.size() * 8);
+            struct G { qe_ctx *c; void *p; ~G() { c->pool.release(p); } } g{ctx, d_partial};
+            p.agg_partial = d_partial;
+            p.ntiles = ntiles;
+            launch_fused(ctx, *plan, p, grid);
+            QE_HIP(hipMemcpyAsync(partial.data(), d_partial, partial.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            collect_time(ctx);
+        }
+        int64_t nsel = 0;
+        for (int i = 0; i < nagg; i++) {
+            const int fn = agg_fns[i];
+            double acc = fn == QE_AGG_MIN ? INFINITY : fn == QE_AGG_MAX ? -INFINITY : 0.0;
+            double cnt = 0;
+            if (ntiles > 0)
+                for (int b = 0; b < grid; b++) {
+                    const double a = partial[(size_t)b * stride + 2 * i], c = partial[(size_t)b * stride + 2 * i + 1];
+                    cnt += c;
+                    if (fn == QE_AGG_MIN) acc = (a != a || acc != acc) ? (acc != acc ? acc : a)
+                                              : (a == 0.0 && acc == 0.0 ? (std::signbit(acc) ? acc : a) : std::min(acc, a));
+                    else if (fn == QE_AGG_MAX) acc = (a != a || acc != acc) ? (acc != acc ? acc : a)
+                                                   : (a == 0.0 && acc == 0.0 ? (std::signbit(acc) ? a : acc) : std::max(acc, a));
+                    else acc += a;
+                }
+            if (fn == QE_AGG_COUNT) {           // Accumulators.kt:26-36
+                out_values[i] = cnt;
+                out_valid[i] = 1;
+            } else if (cnt == 0) {              // :47-53 empty => null
+                out_values[i] = 0.0;
+                out_valid[i] = 0;
+            } else {
+                out_values[i] = fn == QE_AGG_AVG ? acc / cnt : acc;   // :101-107
+                out_valid[i] = 1;
+            }
+        }
+        if (ntiles > 0)
+            for (int b = 0; b < grid; b++) nsel += (int64_t)partial[(size_t)b * stride + 2 * nagg];
+        if (out_selected_rows) *out_selected_rows = nsel;
+    });
+}
+
+// ---- results ----------------------------------------------------------------------------------------
+int64_t qe_result_count(const qe_result *r) { return r ? r->count : -1; }
+int32_t qe_result_ncols(const qe_result *r) { return r ? (int32_t)r->cols.size() : -1; }
+
+int32_t qe_result_column(const qe_result *r, int32_t col, qe_col_view *out) {
+    if (!r || !out || col < 0 || col >= (int32_t)r->cols.size()) return QE_ERR_INVALID_ARG;
+    const OutColumn &c = r->cols[col];
+    out->type = c.type;
+    out->nullable = c.nullable ? 1 : 0;
+    out->data = c.data;
+    out->validity = c.validity;
+    out->count = r->count;
+    out->dict = c.dict ? &c.dict_handle : nullptr;
+    return QE_OK;
+}
+
+int32_t qe_result_column_to_host(qe_ctx *ctx, const qe_result *r, int32_t col, void *data_out, uint64_t *validity_out) {
+    if (!ctx || !r || col < 0 || col >= (int32_t)r->cols.size()) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        const OutColumn &c = r->cols[col];
+        if (r->count == 0) return;
+        if (data_out)
+            QE_HIP(hipMemcpyAsync(data_out, c.data, column_bytes(c.type, r->count), hipMemcpyDeviceToHost, ctx->stream));
+        if (validity_out) {
+            if (c.validity)
+                QE_HIP(hipMemcpyAsync(validity_out, c.validity, bitmap_bytes(r->count), hipMemcpyDeviceToHost, ctx->stream));
+            else
+                std::memset(validity_out, 0xff, bitmap_bytes(r->count));
+        }
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void qe_result_free(qe_ctx *ctx, qe_result *r) {
+    if (!ctx) return;
+    free_result(ctx, r);
+}
+
+int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, double *out_gbps) {
+    if (!ctx || nbytes < 4096 || reps < 1 || !out_gbps) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        void *buf = ctx->pool.alloc((size_t)nbytes);
+        struct G { qe_ctx *c; void *p; ~G() { c->pool.release(p); } } g{ctx, buf};
+        QE_HIP(hipMemsetAsync(buf, 0x5a, (size_t)nbytes, ctx->stream));
+        launch_stream_read(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        double best = 1e30;
+        for (int r = 0; r < reps; r++) {
+            QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+            launch_stream_read(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8));
+            QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            best = std::min(best, (double)ms);
+        }
+        *out_gbps = (double)(nbytes / 16 * 16) / (best * 1e-3) / 1e9;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// qe_internal.h -- internal structures of libqe_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/qe_hip.h"
+
+namespace qe {
+
+// ---- errors ---------------------------------------------------------------------
+struct Error {
+    int32_t code;
+    std::string msg;
+};
+[[noreturn]] void fail(int32_t code, const std::string &msg);
+void hip_check(hipError_t e, const char *what, const char *file, int line);
+#define QE_HIP(x) ::qe::hip_check((x), #x, __FILE__, __LINE__)
+
+// ---- IR: typed expression tree ------------------------------------------------------
+enum NodeKind { N_COLUMN = 0, N_NUM = 1, N_BOOL = 2, N_STR = 3, N_FN = 4, N_CAST = 5 };
+
+struct Node {
+    int kind = 0;
+    int fn = -1;        // QE_FN_* for N_FN
+    int type = -1;      // QE_* data type of the value this node produces
+    int col = -1;       // N_COLUMN
+    double num = 0.0;   // N_NUM
+    bool bval = false;  // N_BOOL
+    std::string str;    // N_STR
+    std::vector<int> ops;
+};
+
+struct Expr {
+    std::vector<uint8_t> program;  // the serialised postfix program (cache key material)
+    std::vector<Node> nodes;       // children before parents
+    int root = -1;
+    int max_stack = 0;             // MaxStackVisitor analogue
+};
+
+Expr decode_program(const uint8_t *program, size_t len);
+int promote_type(int a, int b);
+const char *type_name(int t);
+const char *fn_name(int fn);
+
+// ---- dictionaries ----------------------------------------------------------------------
+struct DictData {
+    std::vector<std::string> entries;
+    std::unordered_map<std::string, int32_t> index;
+    int32_t find(const std::string &s) const {
+        auto it = index.find(s);
+        return it == index.end() ? -1 : it->second;
+    }
+};
+
+}  // namespace qe
+
+struct qe_dict {
+    std::shared_ptr<qe::DictData> d;
+};
+
+namespace qe {
+
+// ---- device memory pool --------------------------------------------------------------------
+// Result and scratch buffers are recycled across calls so that a re-opened
+// operator (T/SimpleSumBenchmark.java:63-94) does not pay hipMalloc/hipFree
+// (each a device synchronisation) per open().
+class Pool {
+public:
+    void *alloc(size_t bytes);
+    void release(void *p);
+    void trim();
+    ~Pool() { trim_all(); }
+    size_t bytes_in_use = 0, bytes_cached = 0;
+
+private:
+    void trim_all();
+    std::multimap<size_t, void *> free_;
+    std::unordered_map<void *, size_t> live_;
+};
+
+struct Column {
+    int type = 0;
+    void *data = nullptr;            // device
+    uint64_t *validity = nullptr;    // device or null
+    std::shared_ptr<DictData> dict;  // QE_STRING
+    bool owned = true;
+};
+
+}  // namespace qe
+
+struct qe_batch {
+    int64_t nrows = 0;
+    bool schema_only = false;
+    std::vector<qe::Column> cols;
+};
+
+struct qe_expr {
+    qe::Expr e;
+};
+
+namespace qe {
+
+struct OutColumn {
+    int type = 0;
+    bool nullable = false;
+    void *data = nullptr;          // device: values (BOOLEAN: bitmap words after packing)
+    uint64_t *validity = nullptr;  // device bitmap or null
+    void *bytes_data = nullptr;    // device scratch: BOOLEAN values as bytes before packing
+    uint8_t *bytes_valid = nullptr;// device scratch: validity as bytes before packing
+    std::shared_ptr<DictData> dict;
+    qe_dict dict_handle;
+};
+
+}  // namespace qe
+
+struct qe_result {
+    int64_t count = 0;
+    int64_t capacity = 0;
+    std::vector<qe::OutColumn> cols;
+};
+
+namespace qe {
+
+// ---- bound plan: expression + schema -> generated source + loaded kernel -------------------
+struct BoundColumn {
+    int type;
+    bool nullable;
+    std::shared_ptr<DictData> dict;
+};
+
+struct OutSpec {
+    int type;
+    bool nullable;
+    std::shared_ptr<DictData> dict;
+};
+
+struct FusedGeometry {
+    int threads = 256;
+    int rows_per_lane = 2;
+    int unroll = 4;          // load groups per tile
+    int tile_rows() const { return threads * rows_per_lane * unroll; }
+};
+
+struct CodegenInput {
+    const Expr *filter = nullptr;
+    std::vector<const Expr *> projections;
+    std::vector<int> agg_fns;  // non-empty: aggregate mode (one per projection)
+    std::vector<BoundColumn> schema;
+    int cmp_semantics = QE_CMP_TOTAL_ORDER;
+    FusedGeometry geo;
+    int nontemporal = 1;
+};
+
+struct CodegenOutput {
+    std::string source;
+    std::vector<OutSpec> outs;
+    std::vector<int> used_cols;  // batch column index per kernel column slot
+};
+
+CodegenOutput generate_fused_source(const CodegenInput &in);
+
+struct Kernel {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+};
+
+class Jit {
+public:
+    explicit Jit(std::string cache_dir) : cache_dir_(std::move(cache_dir)) {}
+    ~Jit();
+    // compile (or fetch from memory / disk cache) and load; needs a current device unless load == false
+    Kernel get(const std::string &source, const char *entry, bool load = true);
+    static std::vector<char> compile(const std::string &source);
+    int compiles = 0, disk_hits = 0, mem_hits = 0;
+
+private:
+    std::string cache_dir_;
+    std::unordered_map<std::string, Kernel> loaded_;
+};
+
+struct Plan {
+    CodegenOutput cg;
+    Kernel kernel;
+    FusedGeometry geo;
+    bool aggregate = false;
+};
+
+// kernel parameter block of the generated fused kernel (must match the prelude in qe_codegen.cpp)
+constexpr int kMaxCols = 16;
+constexpr int kMaxOuts = 16;
+struct FusedParams {
+    const void *col[kMaxCols];
+    const unsigned long long *colvalid[kMaxCols];
+    void *out[kMaxOuts];
+    unsigned char *outvalid[kMaxOuts];
+    long long nrows;
+    long long capacity;
+    unsigned long long *desc;    // per-tile look-back descriptors (zeroed per launch)
+    unsigned int *ticket;        // tile ticket counter (zeroed per launch)
+    unsigned long long *total;   // out: number of selected rows
+    unsigned int *error;         // out: nonzero when a bounded spin gave up
+    double *agg_partial;         // aggregate mode: per-workgroup partials
+    long long ntiles;
+};
+
+}  // namespace qe
+
+struct qe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    qe_options opts{};
+    std::string last_error;
+    qe::Pool pool;
+    std::unique_ptr<qe::Jit> jit;
+    std::map<std::string, std::shared_ptr<qe::Plan>> plans;
+    std::string source_scratch;
+    // profiling of the dominant kernel
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0, total_ms = 0.0;
+    int64_t launches = 0;
+    // small persistent device scratch: ticket, total, error (+ pinned host mirror)
+    unsigned int *d_ctrl = nullptr;      // [0]=ticket [1]=error, [2..3]=total (u64)
+    unsigned long long *h_ctrl = nullptr;// pinned: total, error
+};

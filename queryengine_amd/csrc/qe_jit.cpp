@@ -1,0 +1,101 @@
+// qe_jit.cpp -- hiprtc compile + code-object cache for the generated fused kernels.
+//
+// The analogue of BytecodeCompiler.compile's class definition step
+// (evaluator/BytecodeCompiler.kt:15-20,171-174): generated code is compiled
+// once per distinct plan, kept in memory, and persisted as .hsaco files in the
+// JIT cache directory (the reference dumps its generated classes to
+// target/classes, :124-126,167-169).  hiprtc cross-compiles for gfx950 without
+// a device, so build() can pre-populate the cache for prepared plans.
+#include "qe_internal.h"
+
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <fstream>
+
+namespace qe {
+
+static uint64_t fnv1a(const std::string &s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+static const char *kArch = "gfx950";
+
+std::vector<char> Jit::compile(const std::string &source) {
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "qe_fused.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) fail(QE_ERR_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
+    // -ffp-contract=off: the JVM's DMUL;DADD are separately rounded
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        fail(QE_ERR_HIP, std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + "\n" + log);
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return code;
+}
+
+Kernel Jit::get(const std::string &source, const char *entry, bool load) {
+    char key[64];
+    std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source), source.size(), kArch);
+    auto it = loaded_.find(key);
+    if (it != loaded_.end()) {
+        mem_hits++;
+        return it->second;
+    }
+    std::vector<char> code;
+    std::string path;
+    if (!cache_dir_.empty()) {
+        path = cache_dir_ + "/" + key + ".hsaco";
+        std::ifstream f(path, std::ios::binary);
+        if (f) {
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code.empty()) disk_hits++;
+        }
+    }
+    if (code.empty()) {
+        code = compile(source);
+        compiles++;
+        if (!path.empty()) {
+            ::mkdir(cache_dir_.c_str(), 0777);
+            std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+            std::ofstream f(tmp, std::ios::binary);
+            if (f) {
+                f.write(code.data(), (std::streamsize)code.size());
+                f.close();
+                std::rename(tmp.c_str(), path.c_str());
+                std::ofstream src(path.substr(0, path.size() - 6) + ".hip");
+                if (src) src << source;
+            }
+        }
+    }
+    Kernel k;
+    if (!load) return k;
+    QE_HIP(hipModuleLoadData(&k.module, code.data()));
+    QE_HIP(hipModuleGetFunction(&k.fn, k.module, entry));
+    loaded_[key] = k;
+    return k;
+}
+
+Jit::~Jit() {
+    for (auto &kv : loaded_)
+        if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+}
+
+}  // namespace qe

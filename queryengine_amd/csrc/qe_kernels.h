@@ -1,0 +1,17 @@
+// qe_kernels.h -- host-callable launchers of the precompiled (AOT) gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include "../../include/qe_hip.h"
+
+namespace qe {
+
+// synthetic column generator; data/validity are device pointers
+void launch_generate(hipStream_t s, const qe_gen_spec &spec, uint64_t seed, int64_t row_begin, int64_t nrows,
+                     void *data, uint64_t *validity);
+// bytes (0/1 per row) -> bitmap words (row i = word i>>6 bit i&63)
+void launch_pack_bytes(hipStream_t s, const uint8_t *bytes, int64_t n, uint64_t *words);
+// plain streaming read of nbytes (16 B per lane), result folded into sink[0] so nothing is elided
+void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink);
+
+}  // namespace qe

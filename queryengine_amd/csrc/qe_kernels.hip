@@ -1,0 +1,122 @@
+// qe_kernels.hip -- precompiled gfx950 kernels that are not plan-specific:
+// the synthetic column generator, byte->bitmap packing of nullable/boolean
+// outputs, and the streaming-read calibration kernel used for the roofline.
+#include <hip/hip_runtime.h>
+
+#include "qe_kernels.h"
+
+namespace qe {
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+#define QE_GOLDEN 0x9E3779B97F4A7C15ull
+__device__ __forceinline__ u64 gen_raw(u64 seed, int col_id, u64 row) {
+    return mix64(QE_GOLDEN * (u64)(col_id + 1) + row * QE_GOLDEN + seed);
+}
+
+struct GenArgs {
+    int kind, col_id, aux_col_id, null_pct;
+    u64 modulus, seed;
+    i64 offset, row_begin, nrows;
+    double step;
+    void *data;
+    u64 *validity;
+};
+
+// One thread per row, a wave per 64 rows: the validity word of a wave is one __ballot.
+__global__ void __launch_bounds__(256) generate_kernel(const GenArgs a) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 padded = (a.nrows + 63) & ~63ll;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < padded; k += stride) {
+        const bool in = k < a.nrows;
+        const u64 i = (u64)(a.row_begin + k);
+        const u64 x = gen_raw(a.seed, a.col_id, i);
+        if (in) {
+            switch (a.kind) {
+            case QE_GEN_I64_MOD: ((i64 *)a.data)[k] = (i64)(x % a.modulus) + a.offset; break;
+            case QE_GEN_I32_MOD:
+            case QE_GEN_DICT_MOD: ((int *)a.data)[k] = (int)((i64)(x % a.modulus) + a.offset); break;
+            case QE_GEN_F64_UNIT: ((double *)a.data)[k] = (double)(x >> 11) * 0x1.0p-53; break;
+            case QE_GEN_F64_MOD: ((double *)a.data)[k] = (double)((i64)(x % a.modulus) + a.offset); break;
+            case QE_GEN_F64_STEP: ((double *)a.data)[k] = (double)((i64)(x % a.modulus) + a.offset) * a.step; break;
+            case QE_GEN_F64_PRICE: {
+                const u64 q = gen_raw(a.seed, a.aux_col_id, i) % 50 + 1;
+                const u64 cents = 90000 + x % 120000;
+                ((double *)a.data)[k] = (double)(i64)(q * cents) / 100.0;
+                break;
+            }
+            default: break;
+            }
+        }
+        if (a.validity) {
+            const bool valid = in && (mix64(x + QE_GOLDEN) % 100 >= (u64)a.null_pct);
+            const u64 w = __ballot(valid);
+            if ((threadIdx.x & 63) == 0) a.validity[k >> 6] = w;
+        }
+    }
+}
+
+void launch_generate(hipStream_t s, const qe_gen_spec &spec, uint64_t seed, int64_t row_begin, int64_t nrows,
+                     void *data, uint64_t *validity) {
+    if (nrows <= 0) return;
+    GenArgs a;
+    a.kind = spec.kind; a.col_id = spec.col_id; a.aux_col_id = spec.aux_col_id; a.null_pct = spec.null_pct;
+    a.modulus = spec.modulus ? spec.modulus : 1; a.seed = seed; a.offset = spec.offset; a.row_begin = row_begin;
+    a.nrows = nrows; a.step = spec.step; a.data = data; a.validity = (u64 *)validity;
+    const int64_t blocks = (nrows + 255) / 256;
+    const int grid = (int)(blocks < 16384 ? blocks : 16384);
+    hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
+__global__ void __launch_bounds__(256) pack_bytes_kernel(const unsigned char *bytes, i64 n, u64 *words) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 padded = (n + 63) & ~63ll;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < padded; k += stride) {
+        const bool b = k < n && bytes[k] != 0;
+        const u64 w = __ballot(b);
+        if ((threadIdx.x & 63) == 0) words[k >> 6] = w;
+    }
+}
+
+void launch_pack_bytes(hipStream_t s, const uint8_t *bytes, int64_t n, uint64_t *words) {
+    if (n <= 0) return;
+    const int64_t blocks = (n + 255) / 256;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipLaunchKernelGGL(pack_bytes_kernel, dim3(grid), dim3(256), 0, s, bytes, (i64)n, (u64 *)words);
+}
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+// Read-only stream: 16 B per lane per load, 8 independent loads in flight per lane.
+__global__ void __launch_bounds__(256) stream_read_kernel(const u64x2 *src, i64 nvec, u64 *sink) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 acc = 0;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+        u64x2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y;
+    }
+    for (; i < nvec; i += stride) {
+        const u64x2 v = __builtin_nontemporal_load(src + i);
+        acc ^= v.x ^ v.y;
+    }
+    if (acc == 0x0123456789abcdefull) sink[0] = acc;   // practically never: keeps the loads alive
+}
+
+void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink) {
+    const i64 nvec = nbytes / 16;
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
+}
+
+}  // namespace qe

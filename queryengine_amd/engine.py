@@ -1,0 +1,324 @@
+"""Object layer over the C ABI: Context, Dictionary, DeviceBatch, CompiledExpression, Result.
+
+Each class owns one opaque handle of include/qe_hip.h and frees it with the
+matching ``*_free``.  Nothing here computes: all evaluation happens in
+libqe_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import ast as A
+from . import native as N
+from .datatypes import DataType
+from .program import serialize
+from .table import Column, pack_bitmap, unpack_bitmap
+
+_NP = {DataType.DOUBLE: np.float64, DataType.INT64: np.int64, DataType.INT32: np.int32, DataType.STRING: np.int32}
+
+
+class Context:
+    """qe_ctx: one device + one HIP stream.  ``device=None`` -> planning-only (QE_DEVICE_NONE)."""
+
+    def __init__(self, device: Optional[int] = 0, exec_mode: int = N.EXEC_FUSED, cmp_semantics: int = N.CMP_TOTAL_ORDER,
+                 profile: bool = False, result_capacity_rows: int = 0, jit_cache_dir: Optional[str] = None,
+                 tuning: Sequence[int] = ()):
+        self._lib = N.lib()
+        opts = N.Options()
+        opts.struct_size = C.sizeof(N.Options)
+        opts.exec_mode = exec_mode
+        opts.cmp_semantics = cmp_semantics
+        opts.profile = 1 if profile else 0
+        opts.result_capacity_rows = result_capacity_rows
+        opts.jit_cache_dir = jit_cache_dir.encode() if jit_cache_dir else None
+        for i, t in enumerate(tuning):
+            opts.tuning[i] = int(t)
+        h = C.c_void_p()
+        st = self._lib.qe_ctx_create(N.DEVICE_NONE if device is None else device, C.byref(opts), C.byref(h))
+        N.check(None, st)
+        self.handle = h
+        self.device = device
+        self._dicts: Dict[tuple, "Dictionary"] = {}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._dicts.clear()
+            self._lib.qe_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_exec_mode(self, mode: int) -> None:
+        N.check(self.handle, self._lib.qe_ctx_set_exec_mode(self.handle, mode))
+
+    def set_cmp_semantics(self, mode: int) -> None:
+        N.check(self.handle, self._lib.qe_ctx_set_cmp_semantics(self.handle, mode))
+
+    def kernel_time(self):
+        last, total, n = C.c_double(), C.c_double(), C.c_int64()
+        N.check(self.handle, self._lib.qe_ctx_kernel_time(self.handle, C.byref(last), C.byref(total), C.byref(n)))
+        return last.value, total.value, n.value
+
+    def reset_kernel_time(self) -> None:
+        N.check(self.handle, self._lib.qe_ctx_reset_kernel_time(self.handle))
+
+    def synchronize(self) -> None:
+        N.check(self.handle, self._lib.qe_ctx_synchronize(self.handle))
+
+    def trim(self) -> None:
+        N.check(self.handle, self._lib.qe_ctx_trim(self.handle))
+
+    def stream_read_bandwidth(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
+        out = C.c_double()
+        N.check(self.handle, self._lib.qe_stream_read_bandwidth(self.handle, nbytes, reps, C.byref(out)))
+        return out.value
+
+    def dictionary(self, entries: Sequence[str]) -> "Dictionary":
+        key = tuple(entries)
+        d = self._dicts.get(key)
+        if d is None:
+            d = Dictionary(self, entries)
+            self._dicts[key] = d
+        return d
+
+    def compile(self, expr: A.Expression) -> "CompiledExpression":
+        return CompiledExpression(self, expr)
+
+
+class Dictionary:
+    def __init__(self, ctx: Context, entries: Sequence[str]):
+        self.ctx = ctx
+        self.entries = list(entries)
+        enc = [s.encode("utf-8") for s in self.entries]
+        arr = (C.c_char_p * max(1, len(enc)))(*enc)
+        h = C.c_void_p()
+        N.check(ctx.handle, ctx._lib.qe_dict_create(ctx.handle, len(enc), arr, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx._lib.qe_dict_free(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+def _col_descs(ctx: Context, columns: Sequence[Column], keep: list, schema_only: bool = False):
+    descs = (N.ColDesc * max(1, len(columns)))()
+    for j, c in enumerate(columns):
+        descs[j].type = int(c.type)
+        if c.type == DataType.BOOLEAN:
+            data = pack_bitmap(c.data)
+        else:
+            data = np.ascontiguousarray(c.data)
+        keep.append(data)
+        descs[j].data = None if schema_only else data.ctypes.data
+        if c.valid is not None:
+            v = pack_bitmap(c.valid)
+            keep.append(v)
+            descs[j].validity = v.ctypes.data
+        if c.type == DataType.STRING:
+            d = ctx.dictionary(c.dictionary)
+            keep.append(d)
+            descs[j].dict = d.handle
+    return descs
+
+
+class DeviceBatch:
+    """qe_batch: columns resident in HBM ("pin once")."""
+
+    def __init__(self, ctx: Context, handle, keep=None):
+        self.ctx = ctx
+        self.handle = handle
+        self._keep = keep
+
+    @staticmethod
+    def from_columns(ctx: Context, columns: Sequence[Column]) -> "DeviceBatch":
+        keep: list = []
+        nrows = len(columns[0]) if columns else 0
+        descs = _col_descs(ctx, columns, keep)
+        h = C.c_void_p()
+        N.check(ctx.handle, ctx._lib.qe_batch_create(ctx.handle, nrows, len(columns), descs, C.byref(h)))
+        return DeviceBatch(ctx, h, [k for k in keep if isinstance(k, Dictionary)])
+
+    @staticmethod
+    def describe(ctx: Context, columns: Sequence[Column]) -> "DeviceBatch":
+        """Schema-only batch for plan-time work (no device memory)."""
+        keep: list = []
+        nrows = len(columns[0]) if columns else 0
+        descs = _col_descs(ctx, columns, keep, schema_only=True)
+        h = C.c_void_p()
+        N.check(ctx.handle, ctx._lib.qe_batch_describe(ctx.handle, nrows, len(columns), descs, C.byref(h)))
+        return DeviceBatch(ctx, h, keep)
+
+    @staticmethod
+    def generate(ctx: Context, specs: Sequence[N.GenSpec], nrows: int, row_begin: int = 0, seed: int = 42,
+                 keep=None) -> "DeviceBatch":
+        arr = (N.GenSpec * max(1, len(specs)))(*specs)
+        h = C.c_void_p()
+        N.check(ctx.handle, ctx._lib.qe_batch_generate(ctx.handle, seed, row_begin, nrows, len(specs), arr, C.byref(h)))
+        return DeviceBatch(ctx, h, keep)
+
+    @property
+    def nrows(self) -> int:
+        return int(self.ctx._lib.qe_batch_nrows(self.handle))
+
+    @property
+    def ncols(self) -> int:
+        return int(self.ctx._lib.qe_batch_ncols(self.handle))
+
+    def column_type(self, col: int) -> DataType:
+        return DataType(self.ctx._lib.qe_batch_column_type(self.handle, col))
+
+    def column_to_host(self, col: int, row_begin: int = 0, nrows: Optional[int] = None, dictionary=None) -> Column:
+        n = self.nrows - row_begin if nrows is None else nrows
+        t = self.column_type(col)
+        nwords = (n + 63) // 64
+        valid_words = np.zeros(max(1, nwords), dtype=np.uint64)
+        data = np.zeros(max(1, nwords), dtype=np.uint64) if t == DataType.BOOLEAN else np.zeros(max(1, n), dtype=_NP[t])
+        N.check(self.ctx.handle, self.ctx._lib.qe_batch_column_to_host(
+            self.ctx.handle, self.handle, col, row_begin, n, data.ctypes.data, valid_words.ctypes.data))
+        valid = unpack_bitmap(valid_words, n)
+        vals = unpack_bitmap(data, n) if t == DataType.BOOLEAN else data[:n]
+        return Column(t, vals, valid, dictionary)
+
+    def free(self) -> None:
+        if self.handle and self.ctx.handle:
+            self.ctx._lib.qe_batch_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CompiledExpression:
+    """qe_expr: the analogue of the RowCallable returned by compileExpression (Compiler.kt:20-26)."""
+
+    def __init__(self, ctx: Context, expr: A.Expression):
+        self.ctx = ctx
+        self.expr = expr
+        prog = serialize(expr)
+        h = C.c_void_p()
+        N.check(ctx.handle, ctx._lib.qe_expr_compile(ctx.handle, prog, len(prog), C.byref(h)))
+        self.handle = h
+
+    @property
+    def result_type(self) -> DataType:
+        return DataType(self.ctx._lib.qe_expr_result_type(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx._lib.qe_expr_free(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+def _expr_array(exprs: Sequence[CompiledExpression]):
+    return (C.c_void_p * max(1, len(exprs)))(*[e.handle for e in exprs])
+
+
+class Result:
+    """qe_result: compacted output columns in HBM + row count."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    @property
+    def count(self) -> int:
+        return int(self.ctx._lib.qe_result_count(self.handle))
+
+    @property
+    def ncols(self) -> int:
+        return int(self.ctx._lib.qe_result_ncols(self.handle))
+
+    def view(self, col: int) -> N.ColView:
+        v = N.ColView()
+        N.check(self.ctx.handle, self.ctx._lib.qe_result_column(self.handle, col, C.byref(v)))
+        return v
+
+    def column_to_host(self, col: int) -> Column:
+        v = self.view(col)
+        t = DataType(v.type)
+        n = int(v.count)
+        nwords = (n + 63) // 64
+        valid_words = np.zeros(max(1, nwords), dtype=np.uint64)
+        data = np.zeros(max(1, nwords), dtype=np.uint64) if t == DataType.BOOLEAN else np.zeros(max(1, n), dtype=_NP[t])
+        N.check(self.ctx.handle, self.ctx._lib.qe_result_column_to_host(
+            self.ctx.handle, self.handle, col, data.ctypes.data, valid_words.ctypes.data))
+        valid = unpack_bitmap(valid_words, n)
+        vals = unpack_bitmap(data, n) if t == DataType.BOOLEAN else data[:n]
+        dictionary = None
+        if t == DataType.STRING:
+            m = self.ctx._lib.qe_dict_size(v.dict)
+            dictionary = [self.ctx._lib.qe_dict_entry(v.dict, i).decode("utf-8") for i in range(m)]
+        return Column(t, vals, valid, dictionary)
+
+    def to_columns(self) -> List[Column]:
+        return [self.column_to_host(i) for i in range(self.ncols)]
+
+    def free(self) -> None:
+        if self.handle and self.ctx.handle:
+            self.ctx._lib.qe_result_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def filter_project(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                   projections: Sequence[CompiledExpression]) -> Result:
+    """qe_filter_project: Projection(Filter(Scan)) in one call."""
+    h = C.c_void_p()
+    N.check(ctx.handle, ctx._lib.qe_filter_project(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                   _expr_array(projections), len(projections), C.byref(h)))
+    return Result(ctx, h)
+
+
+def prepare(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+            projections: Sequence[CompiledExpression]) -> None:
+    N.check(ctx.handle, ctx._lib.qe_filter_project_prepare(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                           _expr_array(projections), len(projections)))
+
+
+def generated_source(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                     projections: Sequence[CompiledExpression]) -> str:
+    out = C.c_char_p()
+    N.check(ctx.handle, ctx._lib.qe_filter_project_source(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                          _expr_array(projections), len(projections), C.byref(out)))
+    return out.value.decode("utf-8")
+
+
+def filter_aggregate(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                     exprs: Sequence[CompiledExpression], aggs: Sequence[int]):
+    """qe_filter_aggregate: returns ([float|None per aggregate], selected row count)."""
+    n = len(exprs)
+    vals = (C.c_double * max(1, n))()
+    valid = (C.c_uint8 * max(1, n))()
+    nsel = C.c_int64()
+    fns = (C.c_int32 * max(1, n))(*[int(a) for a in aggs])
+    N.check(ctx.handle, ctx._lib.qe_filter_aggregate(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                     _expr_array(exprs), fns, n, vals, valid, C.byref(nsel)))
+    return [float(vals[i]) if valid[i] else None for i in range(n)], int(nsel.value)

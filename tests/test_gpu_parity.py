@@ -1,0 +1,265 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): bit-exact for integer / bitmap / index results; the f64 results are
+also required to be bit-exact here (0 ULP, tighter than the 1 ULP allowed) because the generated
+kernels are compiled with -ffp-contract=off.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from queryengine_amd import (BooleanLiteralExpression, Column, DataType, Function, NumericLiteralExpression,
+                             StringLiteralExpression)
+from queryengine_amd import engine as E
+from queryengine_amd import native as N
+
+from helpers import B, D, I32, I64, S, ExprGen, Fn, assert_columns_equal, col, fn, num, random_column
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(ctx, oracle, cols, flt, projs, mode=None):
+    mode = oracle.BYTECODE_COMPILER if mode is None else mode
+    batch = E.DeviceBatch.from_columns(ctx, cols)
+    cf = ctx.compile(flt) if flt is not None else None
+    cp = [ctx.compile(p) for p in projs]
+    res = E.filter_project(ctx, batch, cf, cp)
+    got = res.to_columns()
+    want = oracle.filter_project(cols, flt, projs, mode)
+    assert res.count == (len(want[0]) if want else res.count)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert_columns_equal(g, w, f"projection {i}")
+    res.free()
+    batch.free()
+    return got
+
+
+def test_config1_a_plus_b_where_a_lt_100(gpu_ctx, oracle):
+    """BASELINE config 1: SELECT a + b FROM t WHERE a < 100 (reference types: DOUBLE)."""
+    rng = np.random.default_rng(1)
+    n = 100_000
+    a = Column(D, rng.integers(0, 1000, n).astype(np.float64))
+    b = Column(D, rng.integers(0, 2 ** 31, n).astype(np.float64))
+    got = run_both(gpu_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(100)),
+                   [fn(Fn.ADD, col("a", 0, D), col("b", 1, D))])
+    assert 0.05 * n < len(got[0]) < 0.15 * n
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 127, 128, 129, 2047, 2048, 2049, 5000, 70001])
+def test_ragged_sizes(gpu_ctx, oracle, n):
+    """empty / ragged inputs around the 64-row bitmap word and the tile size"""
+    rng = np.random.default_rng(n)
+    a = random_column(rng, I64, n, special=False)
+    c = random_column(rng, D, n, null_frac=0.2 if n else 0.0)
+    flt = fn(Fn.AND, fn(Fn.CMP_LT, col("a", 0, I64), num(100)), fn(Fn.CMP_LT, col("c", 1, D), num(0.5)))
+    run_both(gpu_ctx, oracle, [a, c], flt, [fn(Fn.ADD, col("a", 0, I64), col("a", 0, I64)),
+                                            fn(Fn.MUL, col("c", 1, D), num(2.0))])
+
+
+@pytest.mark.parametrize("sel", [0.0, 0.01, 0.5, 1.0])
+def test_selectivity_extremes(gpu_ctx, oracle, sel):
+    rng = np.random.default_rng(7)
+    n = 50_000
+    a = Column(D, rng.random(n))
+    b = random_column(rng, I64, n)
+    run_both(gpu_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(sel)),
+             [col("b", 1, I64), fn(Fn.SUB, col("a", 0, D), num(1.0))])
+
+
+def test_no_filter_projection_only(gpu_ctx, oracle):
+    rng = np.random.default_rng(3)
+    n = 10_000
+    cols = [random_column(rng, D, n, null_frac=0.1), random_column(rng, D, n)]
+    run_both(gpu_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), col("b", 1, D)),
+                                           fn(Fn.DIV, col("a", 0, D), col("b", 1, D)),
+                                           fn(Fn.MOD, col("a", 0, D), col("b", 1, D))])
+
+
+def test_kleene_tables_with_null_columns(gpu_ctx, oracle):
+    """AND / OR / NOT / IF over nullable BOOLEAN columns (CompilerTest.kt:55-65,81-91,107-111 as columns)."""
+    vals = [True, False, None]
+    p = Column.from_values(B, [x for x in vals for _ in vals] * 50)
+    q = Column.from_values(B, [y for _ in vals for y in vals] * 50)
+    P, Q = col("p", 0, B), col("q", 1, B)
+    projs = [fn(Fn.AND, P, Q), fn(Fn.OR, P, Q), fn(Fn.NOT, P),
+             fn(Fn.IF, P, StringLiteralExpression("t"), StringLiteralExpression("f")),
+             fn(Fn.IF, P, Q, fn(Fn.NOT, Q)), fn(Fn.CMP_EQ, P, Q), fn(Fn.CMP_LT, P, Q)]
+    got = run_both(gpu_ctx, oracle, [p, q], None, projs)
+    assert got[0].to_list()[:9] == [True, False, None, False, False, False, None, False, None]
+    assert got[1].to_list()[:9] == [True, True, True, True, False, None, True, None, None]
+    assert got[3].to_list()[:9] == ["t", "t", "t", "f", "f", "f", None, None, None]
+    # filter keeps only non-null true (FilterOperator.kt:20)
+    kept = run_both(gpu_ctx, oracle, [p, q], fn(Fn.OR, P, Q), [P, Q])
+    assert len(kept[0]) == 50 * 5
+
+
+@pytest.mark.parametrize("mode_name", ["total", "ieee"])
+def test_f64_special_values_all_comparisons(gpu_ctx, oracle, mode_name):
+    """NaN / -0.0 / Inf cross product, both comparison semantics."""
+    from helpers import SPECIAL_F64
+    xs = [x for x in SPECIAL_F64 for _ in SPECIAL_F64]
+    ys = [y for _ in SPECIAL_F64 for y in SPECIAL_F64]
+    a, b = Column(D, np.array(xs)), Column(D, np.array(ys))
+    A_, B_ = col("a", 0, D), col("b", 1, D)
+    projs = [fn(f, A_, B_) for f in (Fn.CMP_LT, Fn.CMP_LE, Fn.CMP_GE, Fn.CMP_GT, Fn.CMP_EQ, Fn.CMP_NE)]
+    projs += [fn(f, A_, B_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)] + [fn(Fn.UNARY_MINUS, A_)]
+    projs += [fn(Fn.CMP_LT, A_, num(0.0)), fn(Fn.CMP_GE, A_, num(float("nan"))), fn(Fn.CMP_GT, A_, num(100.0))]
+    if mode_name == "total":
+        gpu_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
+        run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.BYTECODE_COMPILER)
+        run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.INTERPRETER)
+    else:
+        gpu_ctx.set_cmp_semantics(N.CMP_IEEE)
+        try:
+            run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.CLOSURE_COMPILER)
+        finally:
+            gpu_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
+
+
+def test_fma_contraction_is_off(gpu_ctx, oracle):
+    """a + 10*b must round twice like DMUL;DADD."""
+    a = float.fromhex("0x1.acd7053aa42a3p-1")
+    b = float.fromhex("0x1.1ce794bb05232p-1")
+    cols = [Column(D, np.full(300, a)), Column(D, np.full(300, b))]
+    got = run_both(gpu_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), fn(Fn.MUL, num(10.0), col("b", 1, D)))])
+    assert got[0].data[0].hex() == "0x1.99bc5a911af12p+2"
+
+
+def test_integer_extension_wrap_div_mod(gpu_ctx, oracle):
+    from helpers import SPECIAL_I32, SPECIAL_I64
+    xs = [x for x in SPECIAL_I64 for _ in SPECIAL_I64]
+    ys = [y for _ in SPECIAL_I64 for y in SPECIAL_I64]
+    a, b = Column(I64, np.array(xs, dtype=np.int64)), Column(I64, np.array(ys, dtype=np.int64))
+    x32 = [x for x in SPECIAL_I32 for _ in SPECIAL_I32]
+    y32 = [y for _ in SPECIAL_I32 for y in SPECIAL_I32]
+    n = min(len(xs), len(x32))
+    cols = [Column(I64, a.data[:n]), Column(I64, b.data[:n]), Column(I32, np.array(x32[:n], dtype=np.int32)),
+            Column(I32, np.array(y32[:n], dtype=np.int32))]
+    A_, B_, C_, D_ = col("a", 0, I64), col("b", 1, I64), col("c", 2, I32), col("d", 3, I32)
+    projs = [fn(f, A_, B_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)]
+    projs += [fn(f, C_, D_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)]
+    projs += [fn(Fn.ADD, A_, C_), fn(Fn.MUL, C_, num(1.5)), fn(Fn.UNARY_MINUS, A_), fn(Fn.UNARY_MINUS, C_),
+              fn(Fn.CMP_LT, A_, B_), fn(Fn.CMP_EQ, A_, C_), fn(Fn.CMP_GE, C_, num(100.0)), fn(Fn.CMP_LE, A_, num(99.5))]
+    run_both(gpu_ctx, oracle, cols, None, projs)
+
+
+def test_integers_within_2_53_match_double_only_reference(gpu_ctx, oracle):
+    """with |values| <= 2^53 the INT64 extension equals the DOUBLE-only reference."""
+    rng = np.random.default_rng(11)
+    n = 20_000
+    ai = rng.integers(0, 1000, n, dtype=np.int64)
+    bi = rng.integers(0, 2 ** 31, n, dtype=np.int64)
+    flt_i = fn(Fn.CMP_LT, col("a", 0, I64), num(100))
+    got = run_both(gpu_ctx, oracle, [Column(I64, ai), Column(I64, bi)], flt_i, [fn(Fn.ADD, col("a", 0, I64), col("b", 1, I64))])
+    ref = oracle.filter_project([Column(D, ai.astype(np.float64)), Column(D, bi.astype(np.float64))],
+                                fn(Fn.CMP_LT, col("a", 0, D), num(100)), [fn(Fn.ADD, col("a", 0, D), col("b", 1, D))],
+                                oracle.BYTECODE_COMPILER)
+    assert np.array_equal(got[0].data.astype(np.float64), ref[0].data)
+
+
+def test_dictionary_equality_and_gather_project(gpu_ctx, oracle):
+    """BASELINE config 4 shape: SELECT s, v FROM t WHERE s = 'k0042'"""
+    rng = np.random.default_rng(5)
+    n = 40_000
+    d = ["k%04d" % i for i in range(1000)]
+    s = random_column(rng, S, n, null_frac=0.05, dictionary=d)
+    v = Column(D, rng.random(n))
+    Sx, V = col("s", 0, S), col("v", 1, D)
+    got = run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("k0042")), [Sx, V])
+    assert set(got[0].to_list()) <= {"k0042"}
+    run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_NE, Sx, StringLiteralExpression("nope")), [Sx])
+    run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("nope")), [Sx, V])
+    run_both(gpu_ctx, oracle, [s, v], None,
+             [fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), Sx, StringLiteralExpression("other")),
+              fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), StringLiteralExpression("k0001"), Sx),
+              fn(Fn.CMP_EQ, Sx, Sx)])
+
+
+def test_q6_shape(gpu_ctx, oracle):
+    """BASELINE config 3 shape: TPC-H Q6 predicate, int32 dates, f64 price/discount/quantity."""
+    rng = np.random.default_rng(6)
+    n = 60_000
+    ship = Column(I32, rng.integers(8036, 10562, n, dtype=np.int32))
+    disc = Column(D, rng.integers(0, 11, n).astype(np.float64) * 0.01)
+    qty = Column(D, rng.integers(1, 51, n).astype(np.float64))
+    price = Column(D, np.round(qty.data * rng.uniform(900, 2100, n), 2))
+    SH, DI, QT, PR = col("l_shipdate", 0, I32), col("l_discount", 1, D), col("l_quantity", 2, D), col("l_extendedprice", 3, D)
+    flt = fn(Fn.AND, fn(Fn.AND, fn(Fn.AND, fn(Fn.AND, fn(Fn.CMP_GE, SH, num(8766)), fn(Fn.CMP_LT, SH, num(9131))),
+                                   fn(Fn.CMP_GE, DI, num(0.05))), fn(Fn.CMP_LE, DI, num(0.07))), fn(Fn.CMP_LT, QT, num(24)))
+    got = run_both(gpu_ctx, oracle, [ship, disc, qty, price], flt, [fn(Fn.MUL, PR, DI)])
+    assert 0 < len(got[0]) < n * 0.05
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_expression_trees(gpu_ctx, oracle, seed):
+    """Differential test in the spirit of CompilerTest's @EnumSource(Mode): random typed trees,
+    null-heavy data with NaN/-0.0/extreme integers, GPU vs oracle."""
+    rnd = random.Random(seed)
+    rng = np.random.default_rng(seed)
+    n = 3000 + seed * 17
+    schema = [("a", D), ("b", D), ("i", I64), ("j", I32), ("p", B), ("q", B), ("s", S)]
+    dictionary = ["k%04d" % i for i in range(8)]
+    cols = [random_column(rng, t, n, null_frac=rnd.choice([0.0, 0.1, 0.5]), dictionary=dictionary) for _, t in schema]
+    g = ExprGen(rnd, schema)
+    g.dicts = {"s": dictionary}
+    for _ in range(4):
+        flt = g.boolean(3) if rnd.random() < 0.8 else None
+        projs = [g.numeric(3) if rnd.random() < 0.7 else g.boolean(2) for _ in range(rnd.randint(1, 3))]
+        run_both(gpu_ctx, oracle, cols, flt, projs)
+
+
+def test_generator_matches_oracle(gpu_ctx, oracle):
+    """qe_batch_generate (device) == qo_generate (oracle) for every generator kind, global row index."""
+    import ctypes as C
+    kinds = [(N.GEN_I64_MOD, np.int64, dict(modulus=1000)), (N.GEN_I64_MOD, np.int64, dict(modulus=2 ** 31, offset=-5)),
+             (N.GEN_I32_MOD, np.int32, dict(modulus=2526, offset=8036)), (N.GEN_F64_UNIT, np.float64, {}),
+             (N.GEN_F64_MOD, np.float64, dict(modulus=1000)), (N.GEN_F64_STEP, np.float64, dict(modulus=11, step=0.01)),
+             (N.GEN_F64_PRICE, np.float64, dict(aux_col_id=2))]
+    specs, ospecs = [], []
+    for cid, (kind, _, kw) in enumerate(kinds):
+        s = N.GenSpec(); s.kind = kind; s.col_id = cid; s.modulus = kw.get("modulus", 0); s.offset = kw.get("offset", 0)
+        s.step = kw.get("step", 0.0); s.aux_col_id = kw.get("aux_col_id", 0); s.null_pct = 1 if cid % 2 else 0
+        specs.append(s)
+        o = oracle.GenSpec(); o.kind = kind; o.col_id = cid; o.modulus = s.modulus; o.offset = s.offset; o.step = s.step
+        o.aux_col_id = s.aux_col_id; o.null_pct = s.null_pct
+        ospecs.append(o)
+    n, row_begin = 10_000 + 37, 1 << 33
+    batch = E.DeviceBatch.generate(gpu_ctx, specs, n, row_begin=row_begin, seed=42)
+    for cid, (kind, npdt, _) in enumerate(kinds):
+        got = batch.column_to_host(cid)
+        data, valid = oracle.generate(ospecs[cid], 42, row_begin, n, npdt)
+        want = Column(got.type, data, valid)
+        assert_columns_equal(got, want, f"generator kind {kind}")
+    batch.free()
+
+
+def test_large_batch_properties(gpu_ctx, oracle):
+    """Size-independent properties at a size the oracle cannot walk: count == popcount of the predicate
+    evaluated by an independent plan, order preservation (projected row ids strictly increasing),
+    and idempotence (second run identical)."""
+    n = 50_000_000
+    s0 = N.GenSpec(); s0.kind = N.GEN_I64_MOD; s0.col_id = 0; s0.modulus = 1000
+    s1 = N.GenSpec(); s1.kind = N.GEN_F64_UNIT; s1.col_id = 2
+    batch = E.DeviceBatch.generate(gpu_ctx, [s0, s1], n)
+    A_, C_ = col("a", 0, I64), col("c", 1, D)
+    flt = fn(Fn.AND, fn(Fn.CMP_LT, A_, num(100)), fn(Fn.CMP_LT, C_, num(0.5)))
+    cf = gpu_ctx.compile(flt)
+    proj = [gpu_ctx.compile(C_), gpu_ctx.compile(fn(Fn.ADD, A_, A_))]
+    r1 = E.filter_project(gpu_ctx, batch, cf, proj)
+    c1 = r1.to_columns()
+    # independent count through the aggregate path
+    vals, nsel = E.filter_aggregate(gpu_ctx, batch, cf, [gpu_ctx.compile(C_)], [N.AGG_COUNT])
+    assert r1.count == nsel == int(vals[0])
+    assert abs(r1.count / n - 0.05) < 0.001
+    assert np.all(c1[0].data < 0.5) and np.all(c1[1].data < 200) and np.all(c1[1].data % 2 == 0)
+    # oracle on a prefix: the first rows of the result are exactly the oracle's result on the first 200k rows
+    m = 200_000
+    pa, pc = batch.column_to_host(0, 0, m), batch.column_to_host(1, 0, m)
+    want = oracle.filter_project([pa, pc], flt, [C_, fn(Fn.ADD, A_, A_)], oracle.BYTECODE_COMPILER)
+    k = len(want[0])
+    assert np.array_equal(c1[0].data[:k], want[0].data) and np.array_equal(c1[1].data[:k], want[1].data)
+    r2 = E.filter_project(gpu_ctx, batch, cf, proj)
+    c2 = r2.to_columns()
+    assert np.array_equal(c1[0].data, c2[0].data) and np.array_equal(c1[1].data, c2[1].data)
+    r1.free(); r2.free(); batch.free()
