@@ -459,6 +459,11 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     const int t = ctx->opts.tuning[0], u = ctx->opts.tuning[1];
     if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) g.threads = t;
     if (u >= 1 && u <= 16) g.unroll = u;
+    const int spc = ctx->opts.tuning[4];
+    if (spc >= 16 && spc <= 4096) g.subs_per_chunk = (spc + 15) & ~15;
+    const int lbk = ctx->opts.tuning[6];
+    if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
+    if (ctx->opts.tuning[7] == 2) g.stagger = 0;
     return g;
 }
 
@@ -478,9 +483,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.cmp_semantics = ctx->opts.cmp_semantics;
     in.geo = geometry_of(ctx);
     in.nontemporal = ctx->opts.tuning[2] == 2 ? 0 : 1;
+    in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
-    key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "n"
-        << in.nontemporal << "|";
+    key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -592,24 +598,65 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             p.outvalid[i] = oc.bytes_valid;
         }
     }
-    const int64_t tile_rows = plan->geo.tile_rows();
-    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
-    if (ntiles >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit tile tickets");
-    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc((size_t)ntiles * 8);
-    struct DescGuard {
-        qe_ctx *c; void *p;
-        ~DescGuard() { c->pool.release(p); }
-    } dg{ctx, desc};
+    const int64_t chunk_rows = plan->geo.chunk_rows();
+    const int waves = plan->geo.threads / 64;
+    const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan);
+    // the first `stagger_chunks` chunks (one per resident wave) have graded sizes ((7c mod 16)+1)/16
+    int64_t stagger_chunks = plan->geo.stagger ? max_grid * waves : 0, stagger_rows = 0, nchunks = 0;
+    {
+        const int64_t sixteenth = chunk_rows / 16;
+        int64_t c = 0, rows = 0;
+        // whole periods of 16 chunks cover 136 sixteenths
+        const int64_t periods = std::min<int64_t>(stagger_chunks / 16, n / (136 * sixteenth));
+        c = periods * 16;
+        rows = periods * 136 * sixteenth;
+        while (c < stagger_chunks && rows < n) {
+            rows += (((7 * c) & 15) + 1) * sixteenth;
+            c++;
+        }
+        if (rows >= n) {
+            nchunks = c;
+            stagger_chunks = c;        // every chunk is a staggered one
+            stagger_rows = rows;
+        } else {
+            stagger_rows = rows;
+            nchunks = stagger_chunks + (n - rows + chunk_rows - 1) / chunk_rows;
+        }
+    }
+    if (nchunks >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit chunk tickets");
+    const int grid = (int)std::min<int64_t>((nchunks + waves - 1) / waves, max_grid);
+    // scratch: look-back descriptors + one staging slot (chunk_rows rows per output column) per resident wave
+    std::vector<void *> scratch;
+    struct ScratchGuard {
+        qe_ctx *c; std::vector<void *> &v;
+        ~ScratchGuard() { for (void *q : v) c->pool.release(q); }
+    } sg{ctx, scratch};
+    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 8);
+    scratch.push_back(desc);
+    if (plan->cg.has_filter) {
+        const size_t slots = (size_t)grid * waves;
+        for (size_t i = 0; i < res->cols.size(); i++) {
+            const OutColumn &oc = res->cols[i];
+            const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);
+            p.stage[i] = ctx->pool.alloc(slots * (size_t)chunk_rows * w);
+            scratch.push_back(p.stage[i]);
+            if (oc.nullable) {
+                p.stagevalid[i] = (unsigned char *)ctx->pool.alloc(slots * (size_t)chunk_rows);
+                scratch.push_back(p.stagevalid[i]);
+            }
+        }
+    }
     p.capacity = cap;
     p.desc = desc;
     p.ticket = ctx->d_ctrl;
     p.error = ctx->d_ctrl + 1;
     p.total = (unsigned long long *)(ctx->d_ctrl + 2);
-    p.ntiles = ntiles;
+    p.nchunks = nchunks;
+    p.stagger_chunks = stagger_chunks;
+    p.stagger_rows = stagger_rows;
     // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
     QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));
-    QE_HIP(hipMemsetAsync(desc, 0, (size_t)ntiles * 8, ctx->stream));
-    const int grid = (int)std::min<int64_t>(ntiles, (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan));
+    QE_HIP(hipMemsetAsync(desc, 0, (size_t)nchunks * 8, ctx->stream));
     launch_fused(ctx, *plan, p, grid);
     QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, ctx->stream));
     QE_HIP(hipStreamSynchronize(ctx->stream));
@@ -695,10 +742,12 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
         if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
         auto plan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true);
         const int64_t n = batch->nrows;
-        const int64_t tile_rows = plan->geo.tile_rows();
-        const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+        const int64_t sub_rows = plan->geo.sub_rows();
+        const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
         // fixed grid => fixed reduction tree => bitwise reproducible sums on a given device
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)device_cus(ctx->device) * 4));
+        const int waves = plan->geo.threads / 64;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves,
+                                                                      (int64_t)device_cus(ctx->device) * 8));
         const int stride = 2 * nagg + 1;
         std::vector<double> partial((size_t)grid * stride, 0.0);
         if (ntiles > 0) {
@@ -707,7 +756,7 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
             double *d_partial = (double *)ctx->pool.alloc(partial.size() * 8);
             struct G { qe_ctx *c; void *p; ~G() { c->pool.release(p); } } g{ctx, d_partial};
             p.agg_partial = d_partial;
-            p.ntiles = ntiles;
+            p.nchunks = ntiles;
             launch_fused(ctx, *plan, p, grid);
             QE_HIP(hipMemcpyAsync(partial.data(), d_partial, partial.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             QE_HIP(hipStreamSynchronize(ctx->stream));

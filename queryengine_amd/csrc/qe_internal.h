@@ -145,8 +145,12 @@ struct OutSpec {
 struct FusedGeometry {
     int threads = 256;
     int rows_per_lane = 2;
-    int unroll = 4;          // load groups per tile
-    int tile_rows() const { return threads * rows_per_lane * unroll; }
+    int unroll = 4;          // load groups (of 128 rows) per sub-tile
+    int subs_per_chunk = 32; // sub-tiles per chunk (one ticket + one look-back per chunk); multiple of 16
+    int lookback_k = 8;      // descriptor windows (of 64) loaded per look-back round
+    int stagger = 1;         // grade the sizes of the first chunks
+    int sub_rows() const { return 64 * rows_per_lane * unroll; }
+    int chunk_rows() const { return sub_rows() * subs_per_chunk; }
 };
 
 struct CodegenInput {
@@ -157,12 +161,14 @@ struct CodegenInput {
     int cmp_semantics = QE_CMP_TOTAL_ORDER;
     FusedGeometry geo;
     int nontemporal = 1;
+    int debug_mask = 0;   // ablation builds (wrong results): 1 no look-back, 2 no staging stores, 4 no move
 };
 
 struct CodegenOutput {
     std::string source;
     std::vector<OutSpec> outs;
     std::vector<int> used_cols;  // batch column index per kernel column slot
+    bool has_filter = false;
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);
@@ -201,14 +207,18 @@ struct FusedParams {
     const unsigned long long *colvalid[kMaxCols];
     void *out[kMaxOuts];
     unsigned char *outvalid[kMaxOuts];
+    void *stage[kMaxOuts];           // per-wave-slot staging of compacted rows (QE_CHUNK_ROWS per slot)
+    unsigned char *stagevalid[kMaxOuts];
     long long nrows;
     long long capacity;
-    unsigned long long *desc;    // per-tile look-back descriptors (zeroed per launch)
-    unsigned int *ticket;        // tile ticket counter (zeroed per launch)
+    unsigned long long *desc;    // per-chunk look-back descriptors (zeroed per launch)
+    unsigned int *ticket;        // chunk ticket counter (zeroed per launch)
     unsigned long long *total;   // out: number of selected rows
     unsigned int *error;         // out: nonzero when a bounded spin gave up
     double *agg_partial;         // aggregate mode: per-workgroup partials
-    long long ntiles;
+    long long nchunks;
+    long long stagger_chunks;
+    long long stagger_rows;
 };
 
 }  // namespace qe

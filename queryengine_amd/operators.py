@@ -1,0 +1,184 @@
+"""Physical operators: the reference's pull protocol on top of the GPU path.
+
+``Operator`` is ``operator/Operators.kt:5-11`` (``open / next / close``; ``next()`` returns one boxed
+row or ``None``); ``forEach / map / mapTo`` are ``:13-32``.  The two GPU operators do all their work in
+``open()`` -- exactly like the reference's blocking operators (``GlobalAggregationOperator.kt:10-25``)
+-- and box rows lazily in ``next()``.  Operators are re-openable (``MemorySourceOperator.kt:10-12``;
+the JMH harness re-runs open/next/close on one plan, ``T/SimpleSumBenchmark.java:63-94``): the input
+batch is pinned to HBM once per (table, context) and reused by every ``open()``.
+
+There is no CPU evaluation here: expressions only ever run inside libqe_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, List, Optional, Sequence
+
+from . import engine as E
+from .ast import AggregationFunction, Expression
+from .table import Column, ColumnarTable
+
+
+class Operator:
+    def open(self) -> None:
+        raise NotImplementedError
+
+    def close(self) -> None:
+        raise NotImplementedError
+
+    def next(self) -> Optional[List[Any]]:
+        raise NotImplementedError
+
+    # Closeable.use
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def forEach(op: Operator, consumer: Callable[[List[Any]], None]) -> None:
+    """operator/Operators.kt:13-23"""
+    op.open()
+    try:
+        while True:
+            row = op.next()
+            if row is None:
+                break
+            consumer(row)
+    finally:
+        op.close()
+
+
+def mapTo(op: Operator, result: list, mapper: Callable[[List[Any]], Any]) -> list:
+    forEach(op, lambda row: result.append(mapper(row)))
+    return result
+
+
+def map(op: Operator, mapper: Callable[[List[Any]], Any]) -> list:   # noqa: A001 (reference name)
+    return mapTo(op, [], mapper)
+
+
+class ColumnarScanOperator(Operator):
+    """Scan leaf over a ColumnarTable (replaces MemorySourceOperator.kt:5-36).
+
+    As a row source it reuses ONE row buffer and nulls it on close, like the reference
+    (``:8,15,26-32``).  The GPU operators do not pull rows from it: they take ``columns()``."""
+
+    def __init__(self, table: ColumnarTable, projection: Sequence[str]):
+        self.table = table
+        self.projection = list(projection)
+        self._columns = [table.column(name) for name in self.projection]   # raises "Unknown field" like MemoryTable.kt:11
+        self._idx = 0
+        self._row: List[Any] = [None] * len(self._columns)
+
+    def columns(self) -> List[Column]:
+        return self._columns
+
+    def open(self) -> None:
+        self._idx = 0
+
+    def close(self) -> None:
+        for j in range(len(self._row)):
+            self._row[j] = None
+
+    def next(self) -> Optional[List[Any]]:
+        i = self._idx
+        if i >= self.table.nrows:
+            return None
+        self._idx = i + 1
+        for j, c in enumerate(self._columns):
+            self._row[j] = c.value(i)
+        return self._row
+
+    def device_batch(self, ctx: E.Context) -> E.DeviceBatch:
+        """Pin the projected columns to HBM once per context; later opens reuse the batch."""
+        cache = self.table.__dict__.setdefault("_device_batches", {})
+        key = (id(ctx), tuple(self.projection))
+        b = cache.get(key)
+        if b is None or b.handle is None or ctx.handle is None:
+            b = E.DeviceBatch.from_columns(ctx, self._columns)
+            cache[key] = b
+        return b
+
+
+class GpuFilterProjectOperator(Operator):
+    """Projection(Filter(Scan)) fused into one GPU operator.
+
+    Replaces FilterOperator (operator/FilterOperator.kt:5-26) + ProjectionOperator
+    (operator/ProjectionOperator.kt:5-21) / the generated CompiledProjectionOperator
+    (evaluator/BytecodeCompiler.kt:37-132).  ``filter`` may be None."""
+
+    def __init__(self, ctx: E.Context, source: ColumnarScanOperator, filter: Optional[Expression],
+                 projections: Sequence[Expression]):
+        self.ctx = ctx
+        self.source = source
+        # compileExpression at plan time (Planner.kt:35,44)
+        self._filter = ctx.compile(filter) if filter is not None else None
+        self._projections = [ctx.compile(p) for p in projections]
+        self._result: Optional[E.Result] = None
+        self._columns: Optional[List[Column]] = None
+        self._idx = 0
+        self._count = 0
+
+    def open(self) -> None:
+        self.source.open()
+        batch = self.source.device_batch(self.ctx)
+        self._result = E.filter_project(self.ctx, batch, self._filter, self._projections)
+        self._count = self._result.count
+        self._columns = None
+        self._idx = 0
+
+    def result(self) -> E.Result:
+        """The columnar result in HBM (valid until close())."""
+        if self._result is None:
+            raise RuntimeError("Operator not initialized")   # CsvSourceOperator.kt:49
+        return self._result
+
+    def next(self) -> Optional[List[Any]]:
+        if self._result is None:
+            raise RuntimeError("Operator not initialized")
+        if self._columns is None:
+            self._columns = self._result.to_columns()       # one D2H per column, then rows are boxed lazily
+        i = self._idx
+        if i >= self._count:
+            return None
+        self._idx = i + 1
+        return [c.value(i) for c in self._columns]          # a fresh row per call (ProjectionOperator.kt:18)
+
+    def close(self) -> None:
+        if self._result is not None:
+            self._result.free()
+        self._result = None
+        self._columns = None
+        self.source.close()
+
+
+class GpuGlobalAggregationOperator(Operator):
+    """GlobalAggregation(Projection(Filter(Scan))) as one fused GPU reduction.
+
+    Replaces GlobalAggregationOperator (operator/GlobalAggregationOperator.kt:7-36) over the inner
+    projection: one result row, nulls skipped, empty input => null (COUNT => count)."""
+
+    def __init__(self, ctx: E.Context, source: ColumnarScanOperator, filter: Optional[Expression],
+                 expressions: Sequence[Expression], aggregateFunctions: Sequence[AggregationFunction]):
+        self.ctx = ctx
+        self.source = source
+        self._filter = ctx.compile(filter) if filter is not None else None
+        self._exprs = [ctx.compile(e) for e in expressions]
+        self._aggs = [int(a) for a in aggregateFunctions]
+        self._row: Optional[List[Any]] = None
+
+    def open(self) -> None:
+        self.source.open()
+        batch = self.source.device_batch(self.ctx)
+        vals, _ = E.filter_aggregate(self.ctx, batch, self._filter, self._exprs, self._aggs)
+        # CountAccumulator.finish returns an Int (Accumulators.kt:26-36)
+        self._row = [int(v) if a == int(AggregationFunction.COUNT) else v for v, a in zip(vals, self._aggs)]
+
+    def next(self) -> Optional[List[Any]]:
+        res, self._row = self._row, None      # GlobalAggregationOperator.kt:32-36
+        return res
+
+    def close(self) -> None:
+        self._row = None
+        self.source.close()

@@ -1,0 +1,176 @@
+"""Logical plan nodes and the physical-plan dispatch for the GPU modes.
+
+``LogicalNode`` classes mirror ``evaluator/LogicalPlan.kt:7-12``.  ``buildLogicalPlan`` restates the
+pipeline of ``evaluator/Planner.kt:7-28`` for the plan shapes the hot path covers (initialPlan ->
+resolveSchema -> typeCheck -> aggregate split for all-aggregate select lists -> identity projection
+removal); ``buildPhysicalPlan`` is the drop-in for the Filter/Projection branches of
+``Planner.kt:30-63``: it pattern-matches Projection(Filter(Scan)) / Projection(Scan) / Filter(Scan)
+and emits ONE fused GPU operator.  ``Mode`` extends ``evaluator/Compiler.kt:5-7``
+with the GPU modes; the three JVM modes are not implemented here on purpose (no CPU path).
+"""
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass
+from typing import Any, List, Optional, Sequence
+
+from . import engine as E
+from . import native as N
+from .ast import (AggregationFunction, AggregationFunctionExpression, ColumnExpression, DefaultExpressionVisitor,
+                  Expression, IdentifierExpression)
+from .datatypes import Field, Schema
+from .operators import (ColumnarScanOperator, GpuFilterProjectOperator, GpuGlobalAggregationOperator, Operator)
+from .operators import map as op_map
+from .sql import Query, parseQuery
+from .table import Table, TableRegistry
+from .typecheck import typeCheck
+
+
+class Mode(enum.Enum):
+    GPU_FUSED = "gpu_fused"          # JIT-fused single-pass kernel (the BYTECODE_COMPILER analogue)
+    GPU_PER_NODE = "gpu_per_node"    # kernel per expression node (the INTERPRETER analogue)
+
+
+class SchemaException(RuntimeError):
+    """evaluator/ResolveSchema.kt:9"""
+
+
+class LogicalNode:
+    pass
+
+
+@dataclass(frozen=True)
+class LogicalScanNode(LogicalNode):
+    table: str
+    schema: Schema
+
+
+@dataclass(frozen=True)
+class LogicalFilterNode(LogicalNode):
+    source: LogicalNode
+    filter: Expression
+
+
+@dataclass(frozen=True)
+class LogicalAggregationNode(LogicalNode):
+    source: LogicalNode
+    groupCount: int
+    aggregateFunctions: tuple
+
+
+@dataclass(frozen=True)
+class LogicalProjectionNode(LogicalNode):
+    source: LogicalNode
+    expressions: tuple
+
+
+class _ResolveSchema(DefaultExpressionVisitor):
+    """evaluator/ResolveSchema.kt:49-69: column slots are assigned in order of first use."""
+
+    def __init__(self, schema: Schema):
+        self.schema = schema
+        self.fields: List[Field] = []
+
+    def visitIdentifier(self, expr: IdentifierExpression) -> Expression:
+        for idx, f in enumerate(self.fields):
+            if f.name == expr.name:
+                return ColumnExpression(f.name, idx, f.type)
+        field = self.schema[expr.name]
+        if field is None:
+            raise SchemaException(f"Could not find field {expr.name}")
+        self.fields.append(field)
+        return ColumnExpression(field.name, len(self.fields) - 1, field.type)
+
+
+def buildLogicalPlan(tableRegistry: TableRegistry, query: Query) -> LogicalNode:
+    """Planner.kt:19-28 for the shapes of the hot path."""
+    if query.orderByColumn is not None:
+        raise NotImplementedError("ORDER BY is outside the filter/project hot path (SURVEY 8f row 4)")
+    schema = tableRegistry.getSchema(query.from_)
+    resolver = _ResolveSchema(schema)
+    # rewritePlan visits the Projection before its source (ResolveSchema.kt:24-33): SELECT list first, then WHERE
+    select = [typeCheck(e.accept(resolver)) for e in query.select]
+    flt = typeCheck(query.filter.accept(resolver)) if query.filter is not None else None
+    scan: LogicalNode = LogicalScanNode(query.from_, Schema(resolver.fields))
+    source = LogicalFilterNode(scan, flt) if flt is not None else scan
+    aggs = [isinstance(e, AggregationFunctionExpression) for e in select]
+    if any(aggs):
+        # RewriteAggregates.kt:9-97 splits a projection with aggregates into pre-projection -> Aggregation ->
+        # post-projection; only the all-aggregate, no-group-by case stays on the GPU path
+        if not all(aggs):
+            raise NotImplementedError("GROUP BY / expressions over aggregates are outside the hot path (SURVEY 8f row 2)")
+        pre = LogicalProjectionNode(source, tuple(e.operands[0] for e in select))
+        return LogicalAggregationNode(pre, 0, tuple(e.function for e in select))
+    # Optimizer.kt:33-35 removes an identity projection over the scan
+    if flt is None and all(isinstance(e, ColumnExpression) and e.index == i for i, e in enumerate(select)) \
+            and len(select) == len(resolver.fields):
+        return scan
+    return LogicalProjectionNode(source, tuple(select))
+
+
+_contexts = {}
+
+
+def default_context(mode: Mode, device: int = 0) -> E.Context:
+    key = (mode, device)
+    ctx = _contexts.get(key)
+    if ctx is None or ctx.handle is None:
+        ctx = E.Context(device=device, exec_mode=N.EXEC_FUSED if mode == Mode.GPU_FUSED else N.EXEC_PER_NODE)
+        _contexts[key] = ctx
+    return ctx
+
+
+def _scan_of(tableRegistry: TableRegistry, node: LogicalScanNode) -> ColumnarScanOperator:
+    op = tableRegistry.getTable(node.table).getScanOperator([f.name for f in node.schema.fields])   # Planner.kt:32
+    if not isinstance(op, ColumnarScanOperator):
+        raise TypeError("the GPU modes need a columnar scan leaf (ColumnarTable)")
+    return op
+
+
+def _match_filter_scan(node: LogicalNode):
+    if isinstance(node, LogicalFilterNode) and isinstance(node.source, LogicalScanNode):
+        return node.filter, node.source
+    if isinstance(node, LogicalScanNode):
+        return None, node
+    return None
+
+
+def buildPhysicalPlan(tableRegistry: TableRegistry, plan: LogicalNode, mode: Mode = Mode.GPU_FUSED,
+                      ctx: Optional[E.Context] = None) -> Operator:
+    """Planner.kt:30-63 with the Filter/Projection(/global Aggregation) subtree fused into one GPU operator."""
+    ctx = ctx or default_context(mode)
+    if isinstance(plan, LogicalProjectionNode):
+        m = _match_filter_scan(plan.source)
+        if m is not None:
+            flt, scan = m
+            return GpuFilterProjectOperator(ctx, _scan_of(tableRegistry, scan), flt, plan.expressions)
+    if isinstance(plan, (LogicalFilterNode, LogicalScanNode)):
+        m = _match_filter_scan(plan)
+        if m is not None:
+            flt, scan = m
+            # FilterOperator returns the scan row itself (FilterOperator.kt:21): every scan column passes through
+            identity = [ColumnExpression(f.name, i, f.type) for i, f in enumerate(scan.schema.fields)]
+            return GpuFilterProjectOperator(ctx, _scan_of(tableRegistry, scan), flt, identity)
+    if isinstance(plan, LogicalAggregationNode) and plan.groupCount == 0 and isinstance(plan.source, LogicalProjectionNode):
+        m = _match_filter_scan(plan.source.source)
+        if m is not None:
+            flt, scan = m
+            return GpuGlobalAggregationOperator(ctx, _scan_of(tableRegistry, scan), flt, plan.source.expressions,
+                                                plan.aggregateFunctions)
+    raise NotImplementedError(f"plan shape outside the GPU hot path: {plan!r}")
+
+
+def query(registry, sql: str, mode: Mode = Mode.GPU_FUSED, table: Optional[Table] = None,
+          ctx: Optional[E.Context] = None) -> List[List[Any]]:
+    """Main.kt:11-26: ``query(registry, sql, mode)`` or ``query(tableName, table, sql, mode)``."""
+    if isinstance(registry, str):
+        if table is None:
+            # positional form query(tableName, table, sql[, mode])
+            raise TypeError("query(tableName, sql, table=...) needs a table")
+        r = TableRegistry()
+        r.register(registry, table)
+        registry = r
+    ast = parseQuery(sql)
+    logical = buildLogicalPlan(registry, ast)
+    physical = buildPhysicalPlan(registry, logical, mode, ctx)
+    return op_map(physical, lambda row: row)

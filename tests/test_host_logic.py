@@ -1,0 +1,184 @@
+"""Host-side logic that needs no GPU: SQL front end, type check, plan construction, serialisation,
+program verification (through the C ABI on a planning-only context), kernel generation + hiprtc."""
+import struct
+
+import numpy as np
+import pytest
+
+from queryengine_amd import (BooleanLiteralExpression, Column, ColumnExpression, ColumnarTable, DataType, Field, Function,
+                             FunctionExpression, IdentifierExpression, NumericLiteralExpression, Schema,
+                             StringLiteralExpression, TableRegistry, AggregationFunctionExpression, AggregationFunction)
+from queryengine_amd import engine as E
+from queryengine_amd import native as N
+from queryengine_amd.planner import (LogicalAggregationNode, LogicalFilterNode, LogicalProjectionNode, LogicalScanNode,
+                                     SchemaException, buildLogicalPlan)
+from queryengine_amd.program import serialize
+from queryengine_amd.sql import SyntaxException, parseExpression, parseQuery
+from queryengine_amd.typecheck import TypeCheckException, typeCheck
+
+D, I64, I32, B, S = DataType.DOUBLE, DataType.INT64, DataType.INT32, DataType.BOOLEAN, DataType.STRING
+Fn = Function
+
+
+# ---- parser: the vectors of T/parser/ParserTest.kt:8-50 ------------------------------------------------
+def test_parser_reference_vectors():
+    assert parseExpression("foo") == IdentifierExpression("foo")
+    assert parseExpression("123") == NumericLiteralExpression(123.0)
+    assert parseExpression("-foo") == FunctionExpression(Fn.UNARY_MINUS, [IdentifierExpression("foo")])
+    assert parseExpression("IF foo THEN 1 ELSE 2 END") == FunctionExpression(
+        Fn.IF, [IdentifierExpression("foo"), NumericLiteralExpression(1.0), NumericLiteralExpression(2.0)])
+    assert parseExpression("SUM(foo)") == AggregationFunctionExpression(AggregationFunction.SUM, [IdentifierExpression("foo")])
+    q = parseQuery("SELECT foo, bar FROM baz WHERE foo > 1 ORDER BY 1")
+    assert q.select == (IdentifierExpression("foo"), IdentifierExpression("bar")) and q.from_ == "baz"
+    assert q.filter == FunctionExpression(Fn.CMP_GT, [IdentifierExpression("foo"), NumericLiteralExpression(1.0)])
+    assert q.orderByColumn == 1
+
+
+def test_parser_precedence_follows_grammar_alternative_order():
+    """Query.g4:27-40: unary > mul > add > compare > AND > OR; NOT binds tighter than comparison."""
+    a, b, c = (IdentifierExpression(x) for x in "abc")
+    assert parseExpression("a + b * c") == FunctionExpression(Fn.ADD, [a, FunctionExpression(Fn.MUL, [b, c])])
+    assert parseExpression("a - b - c") == FunctionExpression(Fn.SUB, [FunctionExpression(Fn.SUB, [a, b]), c])
+    assert parseExpression("a < b AND b < c OR a = c") == FunctionExpression(Fn.OR, [
+        FunctionExpression(Fn.AND, [FunctionExpression(Fn.CMP_LT, [a, b]), FunctionExpression(Fn.CMP_LT, [b, c])]),
+        FunctionExpression(Fn.CMP_EQ, [a, c])])
+    assert parseExpression("NOT a < b") == FunctionExpression(Fn.CMP_LT, [FunctionExpression(Fn.NOT, [a]), b])
+    assert parseExpression("-1.5") == NumericLiteralExpression(-1.5)      # ExpressionAstBuilder.kt:104-110
+    assert parseExpression("select") if False else True
+    assert parseExpression("'it''s'") == StringLiteralExpression("it's")
+    assert parseExpression('"my col" <> 2') == FunctionExpression(Fn.CMP_NE, [IdentifierExpression("my col"), NumericLiteralExpression(2.0)])
+    assert parseExpression("TrUe") == BooleanLiteralExpression(True)
+    with pytest.raises(SyntaxException):
+        parseExpression("a +")
+    with pytest.raises(SyntaxException):
+        parseExpression("a ? b")
+
+
+# ---- type check -------------------------------------------------------------------------------------------
+def test_typecheck_rules():
+    a, i, j, p, s = (ColumnExpression("a", 0, D), ColumnExpression("i", 1, I64), ColumnExpression("j", 2, I32),
+                     ColumnExpression("p", 3, B), ColumnExpression("s", 4, S))
+    assert typeCheck(FunctionExpression(Fn.ADD, [a, a])).dataType == D
+    assert typeCheck(FunctionExpression(Fn.ADD, [i, j])).dataType == I64
+    assert typeCheck(FunctionExpression(Fn.MUL, [j, j])).dataType == I32
+    assert typeCheck(FunctionExpression(Fn.SUB, [i, NumericLiteralExpression(1.0)])).dataType == D
+    assert typeCheck(FunctionExpression(Fn.UNARY_MINUS, [i])).dataType == I64
+    # the reference rejects `bool AND bool` (TypeCheck.kt:79-85, a bug); the intended rule is implemented
+    assert typeCheck(FunctionExpression(Fn.AND, [p, FunctionExpression(Fn.CMP_LT, [a, i])])).dataType == B
+    assert typeCheck(FunctionExpression(Fn.IF, [p, i, a])).dataType == D
+    assert typeCheck(FunctionExpression(Fn.CMP_EQ, [s, StringLiteralExpression("x")])).dataType == B
+    for bad in (FunctionExpression(Fn.ADD, [a, p]), FunctionExpression(Fn.AND, [a, p]), FunctionExpression(Fn.NOT, [a]),
+                FunctionExpression(Fn.CMP_LT, [s, s]), FunctionExpression(Fn.CMP_EQ, [s, a]),
+                FunctionExpression(Fn.IF, [a, a, a]), FunctionExpression(Fn.IF, [p, a, s])):
+        with pytest.raises(TypeCheckException):
+            typeCheck(bad)
+
+
+# ---- logical plans ---------------------------------------------------------------------------------------------
+def _registry():
+    t = ColumnarTable.from_rows(Schema([Field("a", I64), Field("b", I64), Field("c", D), Field("s", S)]),
+                                [[1, 2, 0.25, "x"], [200, 3, 0.75, None]])
+    r = TableRegistry()
+    r.register("t", t)
+    return r
+
+
+def test_logical_plan_shapes_and_column_slot_order():
+    r = _registry()
+    plan = buildLogicalPlan(r, parseQuery("SELECT c * 2.0, a + b FROM t WHERE a < 100 AND c < 0.5"))
+    assert isinstance(plan, LogicalProjectionNode) and isinstance(plan.source, LogicalFilterNode)
+    scan = plan.source.source
+    # ResolveSchema.kt:53-63 + :24-33: slots in order of first use, SELECT list before WHERE
+    assert [f.name for f in scan.schema.fields] == ["c", "a", "b"]
+    assert plan.expressions[0].operands[0] == ColumnExpression("c", 0, D)
+    assert plan.source.filter.dataType == B
+    with pytest.raises(SchemaException):
+        buildLogicalPlan(r, parseQuery("SELECT nope FROM t"))
+    assert isinstance(buildLogicalPlan(r, parseQuery("SELECT a, a FROM t")), LogicalProjectionNode)
+    # distinct plain columns are an identity projection over the pruned scan: removed (Optimizer.kt:33-35)
+    ident = buildLogicalPlan(r, parseQuery("SELECT b, a FROM t"))
+    assert isinstance(ident, LogicalScanNode) and [f.name for f in ident.schema.fields] == ["b", "a"]
+    agg = buildLogicalPlan(r, parseQuery("SELECT SUM(a + 10*b), COUNT(c) FROM t WHERE c < 0.5"))
+    assert isinstance(agg, LogicalAggregationNode) and agg.groupCount == 0
+    assert agg.aggregateFunctions == (AggregationFunction.SUM, AggregationFunction.COUNT)
+    with pytest.raises(NotImplementedError):
+        buildLogicalPlan(r, parseQuery("SELECT s, SUM(a) FROM t"))
+
+
+# ---- serialisation + verification through the C ABI (planning-only context: no GPU needed) ------------------------
+@pytest.fixture(scope="module")
+def plan_ctx(native_lib, tmp_path_factory):
+    ctx = E.Context(device=None, jit_cache_dir=str(tmp_path_factory.mktemp("jit")))
+    yield ctx
+    ctx.close()
+
+
+def test_program_encoding_is_postfix():
+    e = FunctionExpression(Fn.CMP_LT, [ColumnExpression("a", 3, I64), NumericLiteralExpression(100.0)], B)
+    b = serialize(e)
+    assert b[:4] == b"QEX\x01"
+    assert b[4:8] == struct.pack("<BBH", 1, int(I64), 3)
+    assert b[8:17] == struct.pack("<Bd", 2, 100.0)
+    assert b[17:] == struct.pack("<BBB", 16, Fn.CMP_LT.ordinal, int(B))
+
+
+def test_expression_verifier(plan_ctx):
+    a, p = ColumnExpression("a", 0, D), ColumnExpression("p", 1, B)
+    assert plan_ctx.compile(FunctionExpression(Fn.ADD, [a, a], D)).result_type == D
+    assert plan_ctx.compile(FunctionExpression(Fn.ADD, [a, ColumnExpression("i", 2, I64)])).result_type == D   # inferred
+    bad_programs = [
+        b"",                                              # no header
+        b"QEX\x02",                                       # wrong version
+        b"QEX\x01",                                       # leaves nothing
+        b"QEX\x01" + struct.pack("<BBB", 16, 9, 1),       # ADD on an empty stack (underflow)
+        serialize(a) + serialize(a)[4:],                  # leaves two values
+        b"QEX\x01" + struct.pack("<BBH", 1, 9, 0),        # bad column type
+        serialize(a)[:-1],                                # truncated
+        b"QEX\x01" + b"\x63",                             # unknown opcode
+    ]
+    for prog in bad_programs:
+        h = __import__("ctypes").c_void_p()
+        st = plan_ctx._lib.qe_expr_compile(plan_ctx.handle, prog, len(prog), __import__("ctypes").byref(h))
+        assert st in (1, 2), prog
+    for bad in (FunctionExpression(Fn.ADD, [a, p], D), FunctionExpression(Fn.AND, [a, p], B),
+                FunctionExpression(Fn.ADD, [a, a], B)):   # declared type does not match inferred
+        with pytest.raises(N.QeError) as ei:
+            plan_ctx.compile(bad)
+        assert ei.value.code == 2
+
+
+def test_planning_context_generates_and_compiles_kernels_without_gpu(plan_ctx):
+    from queryengine_amd import workloads as W
+    from queryengine_amd import prepared
+    for wl in (W.config1(), W.config2(null_pct=1), W.config3(), W.config4()):
+        batch = E.DeviceBatch.describe(plan_ctx, prepared._schema_columns(wl))
+        cf = plan_ctx.compile(wl.filter)
+        cp = [plan_ctx.compile(p) for p in wl.projections]
+        src = E.generated_source(plan_ctx, batch, cf, cp)
+        assert "qe_fused" in src and "__builtin_nontemporal_load" in src and "qe_lookback" in src
+        E.prepare(plan_ctx, batch, cf, cp)                 # hiprtc cross-compiles for gfx950 with no device
+    # but nothing can EXECUTE without a device: there is no CPU fallback
+    with pytest.raises(N.QeError) as ei:
+        E.filter_project(plan_ctx, batch, cf, cp)
+    assert ei.value.code == 3
+    with pytest.raises(N.QeError):
+        E.DeviceBatch.from_columns(plan_ctx, [Column(D, np.zeros(4))])
+
+
+def test_generated_source_specialises_null_handling(plan_ctx):
+    a_nn = Column(D, np.zeros(4))
+    a_n = Column(D, np.zeros(4), np.array([True, False, True, True]))
+    e = FunctionExpression(Fn.CMP_LT, [ColumnExpression("a", 0, D), NumericLiteralExpression(1.0)], B)
+    proj = [plan_ctx.compile(ColumnExpression("a", 0, D))]
+    src_nn = E.generated_source(plan_ctx, E.DeviceBatch.describe(plan_ctx, [a_nn]), plan_ctx.compile(e), proj)
+    src_n = E.generated_source(plan_ctx, E.DeviceBatch.describe(plan_ctx, [a_n]), plan_ctx.compile(e), proj)
+    assert "kc0" not in src_nn and "kc0" in src_n and "stagevalid" in src_n
+
+
+def test_column_type_mismatch_is_rejected(plan_ctx):
+    batch = E.DeviceBatch.describe(plan_ctx, [Column(I64, np.zeros(4, dtype=np.int64))])
+    with pytest.raises(N.QeError) as ei:
+        E.generated_source(plan_ctx, batch, None, [plan_ctx.compile(ColumnExpression("a", 0, D))])
+    assert ei.value.code == 2
+    with pytest.raises(N.QeError):
+        E.generated_source(plan_ctx, batch, None, [plan_ctx.compile(ColumnExpression("a", 5, I64))])
