@@ -557,6 +557,11 @@ void collect_time(qe_ctx *ctx) {
 void free_result(qe_ctx *ctx, qe_result *r) {
     if (!r) return;
     for (auto &c : r->cols) {
+        if (c.hold_data || c.hold_valid) {   // per-node results share buffers with pool-backed temporaries
+            c.hold_data.reset();
+            c.hold_valid.reset();
+            continue;
+        }
         ctx->pool.release(c.data);
         ctx->pool.release(c.validity);
         ctx->pool.release(c.bytes_data);
@@ -634,7 +639,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     unsigned long long *desc = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 8);
     scratch.push_back(desc);
     if (plan->cg.has_filter) {
-        const size_t slots = (size_t)grid * waves;
+        const size_t slots = (size_t)grid * waves * 2;   // two staging slots per resident wave (deferred resolve)
         for (size_t i = 0; i < res->cols.size(); i++) {
             const OutColumn &oc = res->cols[i];
             const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);

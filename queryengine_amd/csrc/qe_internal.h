@@ -117,6 +117,8 @@ struct OutColumn {
     uint8_t *bytes_valid = nullptr;// device scratch: validity as bytes before packing
     std::shared_ptr<DictData> dict;
     qe_dict dict_handle;
+    // QE_EXEC_PER_NODE: buffers shared with the executor's temporaries (released when reset)
+    std::shared_ptr<void> hold_data, hold_valid;
 };
 
 }  // namespace qe
@@ -145,8 +147,8 @@ struct OutSpec {
 struct FusedGeometry {
     int threads = 256;
     int rows_per_lane = 2;
-    int unroll = 4;          // load groups (of 128 rows) per sub-tile
-    int subs_per_chunk = 32; // sub-tiles per chunk (one ticket + one look-back per chunk); multiple of 16
+    int unroll = 8;          // load groups (of 128 rows) per sub-tile
+    int subs_per_chunk = 16; // sub-tiles per chunk (one ticket + one look-back per chunk); multiple of 16
     int lookback_k = 8;      // descriptor windows (of 64) loaded per look-back round
     int stagger = 1;         // grade the sizes of the first chunks
     int sub_rows() const { return 64 * rows_per_lane * unroll; }

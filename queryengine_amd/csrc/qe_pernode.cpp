@@ -1,6 +1,384 @@
+// qe_pernode.cpp -- QE_EXEC_PER_NODE: the kernel-per-expression-node pipeline on one HIP stream.
+//
+// The on-device analogue of Mode.INTERPRETER's tree walk (evaluator/Interpreter.kt:29-109): every
+// node of the typed tree becomes one launch of a precompiled kernel (qe_pernode_kernels.hip) over
+// whole columns; BOOLEAN values and validity travel as 64-row bitmap words.  The executor is
+// filter-first (late materialisation):
+//   1. evaluate the Filter's nodes over the full batch -> (value, known) bitmaps
+//   2. keep = value & known (FilterOperator.kt:20) -> word popcounts -> scan -> ascending row ids
+//   3. gather only the columns the projections reference at those row ids
+//   4. evaluate the Projection's nodes over the compacted columns
+// It needs no JIT and is the general path; the fused kernel (qe_codegen.cpp) is the fast path.
 #include "qe_pernode.h"
+
+#include <algorithm>
+#include <functional>
+
+#include "qe_pernode_kernels.h"
+
 namespace qe {
-qe_result *run_per_node(qe_ctx *, const qe_batch *, const qe_expr *, const qe_expr *const *, int32_t) {
-    fail(QE_ERR_UNSUPPORTED, "QE_EXEC_PER_NODE is not built yet");
+
+namespace {
+
+using Buf = std::shared_ptr<void>;
+
+struct Vec {
+    int type = -1;
+    bool scalar = false;   // literal broadcast
+    double f = 0.0;
+    long long i = 0;       // INT64 / INT32 / STRING code / BOOLEAN (0|1)
+    Buf data;              // column values, or bitmap words for BOOLEAN
+    Buf valid;             // known-bitmap, null = all valid
+    std::shared_ptr<DictData> dict;
+    bool is_str_lit = false;
+    std::string lit;
+};
+
+size_t width_of(int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 8 : 4; }
+int kernel_type(int t) { return t == QE_STRING ? QE_INT32 : t; }
+int64_t words_of(int64_t n) { return (n + 63) / 64; }
+
+struct Exec {
+    qe_ctx *ctx;
+    hipStream_t s;
+    int64_t n = 0;               // rows of the current domain
+    std::vector<Vec> env;        // batch columns of the current domain
+    int ieee;
+
+    Buf alloc(size_t bytes) {
+        void *p = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        qe_ctx *c = ctx;
+        return Buf(p, [c](void *q) { c->pool.release(q); });
+    }
+    Buf alloc_col(int type) { return alloc(width_of(type) * (size_t)n); }
+    Buf alloc_words() { return alloc((size_t)words_of(n) * 8); }
+
+    pn::Opnd opnd(const Vec &v) {
+        pn::Opnd o;
+        o.ptr = v.scalar ? nullptr : v.data.get();
+        o.f = v.f;
+        o.i = v.i;
+        return o;
+    }
+
+    // literal -> column / bitmap
+    Vec materialize(const Vec &v) {
+        if (!v.scalar) return v;
+        Vec r = v;
+        r.scalar = false;
+        if (v.type == QE_BOOLEAN) {
+            r.data = alloc_words();
+            pn::word_fill(s, v.i ? ~0ull : 0ull, (uint64_t *)r.data.get(), words_of(n));
+        } else {
+            r.data = alloc_col(v.type);
+            pn::fill(s, kernel_type(v.type), opnd(v), r.data.get(), n);
+        }
+        return r;
+    }
+
+    Buf and_valid(const Buf &a, const Buf &b) {
+        if (!a) return b;
+        if (!b) return a;
+        Buf r = alloc_words();
+        pn::word_op(s, pn::W_AND, (const uint64_t *)a.get(), (const uint64_t *)b.get(), (uint64_t *)r.get(), words_of(n));
+        return r;
+    }
+
+    Buf ones() {
+        Buf r = alloc_words();
+        pn::word_fill(s, ~0ull, (uint64_t *)r.get(), words_of(n));
+        return r;
+    }
+
+    Vec eval(const Expr &e, int id) {
+        const Node &nd = e.nodes[id];
+        Vec r;
+        r.type = nd.type;
+        switch (nd.kind) {
+        case N_COLUMN: {
+            if (nd.col < 0 || nd.col >= (int)env.size()) fail(QE_ERR_PROGRAM, "column index out of range");
+            if (env[nd.col].type != nd.type)
+                fail(QE_ERR_PROGRAM, std::string("column ") + std::to_string(nd.col) + " is " + type_name(env[nd.col].type) +
+                                         " in the batch but " + type_name(nd.type) + " in the expression");
+            return env[nd.col];
+        }
+        case N_NUM: r.scalar = true; r.f = nd.num; return r;
+        case N_BOOL: r.scalar = true; r.i = nd.bval ? 1 : 0; return r;
+        case N_STR: r.is_str_lit = true; r.lit = nd.str; r.scalar = true; return r;
+        case N_CAST: {
+            Vec a = eval(e, nd.ops[0]);
+            r.valid = a.valid;
+            if (a.scalar) {   // literals are DOUBLE already; kept for completeness
+                r.scalar = true;
+                r.f = a.type == QE_DOUBLE ? a.f : (double)a.i;
+                r.i = a.i;
+                return r;
+            }
+            r.data = alloc_col(nd.type);
+            pn::cast(s, a.type, nd.type, a.data.get(), r.data.get(), n);
+            return r;
+        }
+        case N_FN: break;
+        default: fail(QE_ERR_INTERNAL, "bad node kind");
+        }
+
+        switch (nd.fn) {
+        case QE_FN_UNARY_PLUS: return eval(e, nd.ops[0]);
+        case QE_FN_UNARY_MINUS: {
+            Vec a = materialize(eval(e, nd.ops[0]));
+            r.valid = a.valid;
+            r.data = alloc_col(nd.type);
+            pn::negate(s, nd.type, a.data.get(), r.data.get(), n);
+            return r;
+        }
+        case QE_FN_ADD: case QE_FN_SUB: case QE_FN_MUL: case QE_FN_DIV: case QE_FN_MOD: {
+            Vec a = eval(e, nd.ops[0]), b = eval(e, nd.ops[1]);
+            if (a.scalar && b.scalar) a = materialize(a);
+            r.valid = and_valid(a.valid, b.valid);
+            const int op = nd.fn == QE_FN_ADD ? pn::A_ADD : nd.fn == QE_FN_SUB ? pn::A_SUB : nd.fn == QE_FN_MUL ? pn::A_MUL
+                         : nd.fn == QE_FN_DIV ? pn::A_DIV : pn::A_MOD;
+            if (nd.type != QE_DOUBLE && (op == pn::A_DIV || op == pn::A_MOD)) {
+                Buf nz = alloc_words();   // integer division by zero => NULL
+                pn::nonzero(s, nd.type, opnd(b), (uint64_t *)nz.get(), n);
+                r.valid = and_valid(r.valid, nz);
+            }
+            r.data = alloc_col(nd.type);
+            pn::arith(s, nd.type, op, opnd(a), opnd(b), r.data.get(), n);
+            return r;
+        }
+        case QE_FN_CMP_LT: case QE_FN_CMP_LE: case QE_FN_CMP_GE: case QE_FN_CMP_GT: case QE_FN_CMP_EQ: case QE_FN_CMP_NE: {
+            Vec a = eval(e, nd.ops[0]), b = eval(e, nd.ops[1]);
+            const int cmp = nd.fn == QE_FN_CMP_LT ? pn::C_LT : nd.fn == QE_FN_CMP_LE ? pn::C_LE : nd.fn == QE_FN_CMP_GE ? pn::C_GE
+                          : nd.fn == QE_FN_CMP_GT ? pn::C_GT : nd.fn == QE_FN_CMP_EQ ? pn::C_EQ : pn::C_NE;
+            const int ot = e.nodes[nd.ops[0]].type;
+            r.valid = and_valid(a.valid, b.valid);
+            if (ot == QE_STRING) {
+                if (cmp != pn::C_EQ && cmp != pn::C_NE)
+                    fail(QE_ERR_UNSUPPORTED, "ordering comparison of STRING values is not supported on the device");
+                if (a.is_str_lit && b.is_str_lit) {
+                    r.scalar = true;
+                    r.i = ((a.lit == b.lit) == (cmp == pn::C_EQ)) ? 1 : 0;
+                    return r;
+                }
+                // String.equals against a literal == code equality (absent literal: code -1, never equal)
+                if (a.is_str_lit) { a.i = b.dict->find(a.lit); a.is_str_lit = false; }
+                else if (b.is_str_lit) { b.i = a.dict->find(b.lit); b.is_str_lit = false; }
+                else if (a.dict != b.dict) fail(QE_ERR_UNSUPPORTED, "comparison of STRING values with different dictionaries");
+                r.data = alloc_words();
+                pn::compare(s, QE_INT32, cmp, 0, opnd(a), opnd(b), (uint64_t *)r.data.get(), n);
+                return r;
+            }
+            if (ot == QE_BOOLEAN) {   // Boolean.compare on bitmaps: false < true
+                Vec x = materialize(a), y = materialize(b);
+                const int w = cmp == pn::C_EQ ? pn::W_XNOR : cmp == pn::C_NE ? pn::W_XOR : cmp == pn::C_LT ? pn::W_NOTAND
+                            : cmp == pn::C_LE ? pn::W_NOTOR : cmp == pn::C_GT ? pn::W_ANDNOT : pn::W_ORNOT;
+                r.data = alloc_words();
+                pn::word_op(s, w, (const uint64_t *)x.data.get(), (const uint64_t *)y.data.get(), (uint64_t *)r.data.get(), words_of(n));
+                return r;
+            }
+            if (a.scalar && b.scalar) a = materialize(a);
+            r.data = alloc_words();
+            pn::compare(s, ot, cmp, ieee, opnd(a), opnd(b), (uint64_t *)r.data.get(), n);
+            return r;
+        }
+        case QE_FN_NOT: {   // ClosureCompiler.kt:115: null -> null
+            Vec a = materialize(eval(e, nd.ops[0]));
+            r.valid = a.valid;
+            r.data = alloc_words();
+            pn::word_not(s, (const uint64_t *)a.data.get(), (uint64_t *)r.data.get(), words_of(n));
+            return r;
+        }
+        case QE_FN_AND: case QE_FN_OR: {
+            Vec a = materialize(eval(e, nd.ops[0])), b = materialize(eval(e, nd.ops[1]));
+            r.data = alloc_words();
+            if (a.valid || b.valid) r.valid = alloc_words();
+            pn::kleene(s, nd.fn == QE_FN_AND, (const uint64_t *)a.data.get(), (const uint64_t *)a.valid.get(),
+                       (const uint64_t *)b.data.get(), (const uint64_t *)b.valid.get(), (uint64_t *)r.data.get(),
+                       (uint64_t *)r.valid.get(), words_of(n));
+            return r;
+        }
+        case QE_FN_IF: {   // Interpreter.kt:46-53: null condition -> null; both branches evaluated, then selected
+            Vec c = materialize(eval(e, nd.ops[0])), t = eval(e, nd.ops[1]), f = eval(e, nd.ops[2]);
+            Buf cond = c.data;
+            if (c.valid) cond = and_valid(c.data, c.valid);   // c = vc & kc
+            if (nd.type == QE_STRING) {
+                // unify dictionaries; the codes of a non-literal side stay valid (its dictionary is a prefix)
+                auto ndct = std::make_shared<DictData>();
+                const Vec *base = !t.is_str_lit ? &t : (!f.is_str_lit ? &f : nullptr);
+                if (!t.is_str_lit && !f.is_str_lit && t.dict != f.dict)
+                    fail(QE_ERR_UNSUPPORTED, "IF over STRING values with different dictionaries");
+                if (base) *ndct = *base->dict;
+                auto resolve = [&](Vec &x) {
+                    if (!x.is_str_lit) return;
+                    int32_t code = ndct->find(x.lit);
+                    if (code < 0) {
+                        code = (int32_t)ndct->entries.size();
+                        ndct->entries.push_back(x.lit);
+                        ndct->index[x.lit] = code;
+                    }
+                    x.i = code;
+                    x.is_str_lit = false;
+                };
+                resolve(t);
+                resolve(f);
+                r.dict = ndct;
+            }
+            if (nd.type == QE_BOOLEAN) {
+                Vec tt = materialize(t), ff = materialize(f);
+                r.data = alloc_words();
+                pn::select_words(s, (const uint64_t *)cond.get(), (const uint64_t *)tt.data.get(), (const uint64_t *)ff.data.get(),
+                                 (uint64_t *)r.data.get(), words_of(n));
+            } else {
+                r.data = alloc_col(nd.type);
+                pn::select(s, kernel_type(nd.type), (const uint64_t *)cond.get(), opnd(t), opnd(f), r.data.get(), n);
+            }
+            if (t.valid || f.valid) {
+                Buf kt = t.valid ? t.valid : ones(), kf = f.valid ? f.valid : ones();
+                Buf sel = alloc_words();
+                pn::select_words(s, (const uint64_t *)cond.get(), (const uint64_t *)kt.get(), (const uint64_t *)kf.get(),
+                                 (uint64_t *)sel.get(), words_of(n));
+                r.valid = and_valid(c.valid, sel);
+            } else {
+                r.valid = c.valid;
+            }
+            return r;
+        }
+        default: fail(QE_ERR_INTERNAL, "bad function");
+        }
+    }
+};
+
+void collect_columns(const Expr &e, std::vector<char> &used) {
+    for (const Node &nd : e.nodes)
+        if (nd.kind == N_COLUMN && nd.col >= 0 && nd.col < (int)used.size()) used[nd.col] = 1;
 }
+
+}  // namespace
+
+qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projs,
+                        int32_t nproj) {
+    if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
+    if (batch->nrows >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "QE_EXEC_PER_NODE uses 32-bit row ids: batch too large");
+    Exec x;
+    x.ctx = ctx;
+    x.s = ctx->stream;
+    x.n = batch->nrows;
+    x.ieee = ctx->opts.cmp_semantics == QE_CMP_IEEE;
+    for (const Column &c : batch->cols) {
+        Vec v;
+        v.type = c.type;
+        v.data = Buf(c.data, [](void *) {});
+        if (c.validity) v.valid = Buf(c.validity, [](void *) {});
+        v.dict = c.dict;
+        x.env.push_back(v);
+    }
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) {
+        for (auto &c : r->cols) {
+            c.hold_data.reset();
+            c.hold_valid.reset();
+        }
+        delete r;
+    });
+    int64_t m = batch->nrows;
+    if (filter && batch->nrows > 0) {
+        const Expr &fe = filter->e;
+        if (fe.nodes[fe.root].type != QE_BOOLEAN) fail(QE_ERR_PROGRAM, "filter expression must be BOOLEAN");
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        Vec keep = x.materialize(x.eval(fe, fe.root));
+        // 2. selection vector
+        const int64_t nw = words_of(x.n);
+        Buf counts = x.alloc((size_t)nw * 4), offsets = x.alloc((size_t)nw * 4), sums = x.alloc((size_t)((nw + 1023) / 1024) * 4 + 16);
+        pn::word_popcounts(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
+                           (uint32_t *)counts.get(), nw);
+        unsigned long long *d_total = (unsigned long long *)(ctx->d_ctrl + 2);
+        pn::exclusive_scan_u32(x.s, (const uint32_t *)counts.get(), (uint32_t *)offsets.get(), (uint32_t *)sums.get(), nw, d_total);
+        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, x.s));
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(x.s));
+        m = (int64_t)ctx->h_ctrl[1];
+        Buf idx = x.alloc((size_t)std::max<int64_t>(m, 1) * 4);
+        pn::expand_indices(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
+                           (const uint32_t *)offsets.get(), (uint32_t *)idx.get(), nw);
+        // 3. gather the referenced columns at the kept row ids
+        std::vector<char> used(x.env.size(), 0);
+        for (int32_t i = 0; i < nproj; i++) collect_columns(projs[i]->e, used);
+        std::vector<Vec> compact(x.env.size());
+        const int64_t full_n = x.n;
+        x.n = m;
+        for (size_t j = 0; j < x.env.size(); j++) {
+            compact[j].type = x.env[j].type;
+            compact[j].dict = x.env[j].dict;
+            if (!used[j]) continue;
+            const Vec &src = x.env[j];
+            if (src.type == QE_BOOLEAN) {
+                compact[j].data = x.alloc_words();
+                pn::gather_bits(x.s, (const uint64_t *)src.data.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].data.get(), m);
+            } else {
+                compact[j].data = x.alloc_col(src.type);
+                pn::gather(x.s, kernel_type(src.type), src.data.get(), (const uint32_t *)idx.get(), compact[j].data.get(), m);
+            }
+            if (src.valid) {
+                compact[j].valid = x.alloc_words();
+                pn::gather_bits(x.s, (const uint64_t *)src.valid.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].valid.get(), m);
+            }
+        }
+        (void)full_n;
+        x.env.swap(compact);
+    } else if (ctx->opts.profile) {
+        QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    }
+    // 4. projections over the (compacted) domain
+    res->count = m;
+    res->capacity = m;
+    for (int32_t i = 0; i < nproj; i++) {
+        if (!projs[i]) fail(QE_ERR_INVALID_ARG, "null projection");
+        const Expr &pe = projs[i]->e;
+        Vec v = x.eval(pe, pe.root);
+        if (v.is_str_lit) {   // SELECT 'lit'
+            auto ndct = std::make_shared<DictData>();
+            ndct->entries.push_back(v.lit);
+            ndct->index[v.lit] = 0;
+            v.dict = ndct;
+            v.i = 0;
+            v.is_str_lit = false;
+        }
+        if (m > 0) v = x.materialize(v);
+        OutColumn oc;
+        oc.type = v.type;
+        oc.dict = v.dict;
+        oc.dict_handle.d = v.dict;
+        oc.nullable = (bool)v.valid;
+        if (m > 0) {
+            // a bare column of an unfiltered batch aliases the caller's input: the result must own its data
+            auto owned = [&](const Buf &b, size_t bytes) -> Buf {
+                if (!b) return b;
+                for (const Column &c : batch->cols)
+                    if (b.get() == c.data || b.get() == (void *)c.validity) {
+                        Buf copy = x.alloc(bytes);
+                        QE_HIP(hipMemcpyAsync(copy.get(), b.get(), bytes, hipMemcpyDeviceToDevice, x.s));
+                        return copy;
+                    }
+                return b;
+            };
+            const size_t dbytes = v.type == QE_BOOLEAN ? (size_t)words_of(m) * 8 : width_of(v.type) * (size_t)m;
+            oc.hold_data = owned(v.data, dbytes);
+            oc.hold_valid = owned(v.valid, (size_t)words_of(m) * 8);
+            oc.data = oc.hold_data.get();
+            oc.validity = (uint64_t *)oc.hold_valid.get();
+        }
+        res->cols.push_back(oc);
+    }
+    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    QE_HIP(hipGetLastError());
+    QE_HIP(hipStreamSynchronize(x.s));
+    if (ctx->opts.profile) {
+        float ms = 0.f;
+        QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_ms = ms;
+        ctx->total_ms += ms;
+        ctx->launches++;
+    }
+    return res.release();
 }
+
+}  // namespace qe

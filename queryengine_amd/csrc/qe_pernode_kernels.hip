@@ -1,0 +1,451 @@
+// qe_pernode_kernels.hip -- one precompiled gfx950 kernel per expression node kind
+// (SURVEY 2.1 kernel inventory): arithmetic, negate, cast, comparison -> bitmap via
+// __ballot, Kleene logic on 64-row words, IF select, and the filter's stable
+// compaction (word popcount -> scan -> index expansion -> gather).
+//
+// Semantics per node follow evaluator/Interpreter.kt:94-107 (JVM DADD..DREM,
+// Double.compare / equals) exactly as the fused kernels do; validity is handled
+// by the executor with word-parallel bitmap kernels (k = ka & kb etc.).
+#include <hip/hip_runtime.h>
+
+#include "qe_pernode_kernels.h"
+#include "../../include/qe_hip.h"
+
+namespace qe {
+namespace pn {
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int u32;
+
+template <typename T> struct Ld {
+    const T *p;
+    T s;
+    __device__ __forceinline__ T operator[](i64 i) const { return p ? p[i] : s; }
+};
+
+template <typename T> static Ld<T> mk(const Opnd &o);
+template <> Ld<double> mk<double>(const Opnd &o) { return Ld<double>{(const double *)o.ptr, o.f}; }
+template <> Ld<i64> mk<i64>(const Opnd &o) { return Ld<i64>{(const i64 *)o.ptr, (i64)o.i}; }
+template <> Ld<int> mk<int>(const Opnd &o) { return Ld<int>{(const int *)o.ptr, (int)o.i}; }
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 16384) {
+    int64_t b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- arithmetic ------------------------------------------------------------------------------------
+template <typename T, int OP> struct ArithOp;
+template <int OP> struct ArithOp<double, OP> {
+    static __device__ __forceinline__ double apply(double a, double b) {
+        if (OP == A_ADD) return a + b;
+        if (OP == A_SUB) return a - b;
+        if (OP == A_MUL) return a * b;
+        if (OP == A_DIV) return a / b;
+        return fmod(a, b);   // DREM
+    }
+};
+template <int OP> struct ArithOp<i64, OP> {
+    static __device__ __forceinline__ i64 apply(i64 a, i64 b) {
+        if (OP == A_ADD) return (i64)((u64)a + (u64)b);
+        if (OP == A_SUB) return (i64)((u64)a - (u64)b);
+        if (OP == A_MUL) return (i64)((u64)a * (u64)b);
+        const i64 d = b == 0 ? 1 : b;   // row is NULL anyway (nonzero bitmap)
+        if (OP == A_DIV) return d == -1 ? (i64)(0ull - (u64)a) : a / d;
+        return d == -1 ? 0 : a % d;
+    }
+};
+template <int OP> struct ArithOp<int, OP> {
+    static __device__ __forceinline__ int apply(int a, int b) {
+        if (OP == A_ADD) return (int)((u32)a + (u32)b);
+        if (OP == A_SUB) return (int)((u32)a - (u32)b);
+        if (OP == A_MUL) return (int)((u32)a * (u32)b);
+        const int d = b == 0 ? 1 : b;
+        if (OP == A_DIV) return d == -1 ? (int)(0u - (u32)a) : a / d;
+        return d == -1 ? 0 : a % d;
+    }
+};
+
+template <typename T, int OP>
+__global__ void __launch_bounds__(256) k_arith(Ld<T> a, Ld<T> b, T *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = ArithOp<T, OP>::apply(a[i], b[i]);
+}
+
+template <typename T> static void arith_t(hipStream_t s, int op, const Opnd &a, const Opnd &b, void *out, int64_t n) {
+    const int g = grid_for(n);
+    Ld<T> la = mk<T>(a), lb = mk<T>(b);
+    switch (op) {
+    case A_ADD: hipLaunchKernelGGL((k_arith<T, A_ADD>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
+    case A_SUB: hipLaunchKernelGGL((k_arith<T, A_SUB>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
+    case A_MUL: hipLaunchKernelGGL((k_arith<T, A_MUL>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
+    case A_DIV: hipLaunchKernelGGL((k_arith<T, A_DIV>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
+    default: hipLaunchKernelGGL((k_arith<T, A_MOD>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
+    }
+}
+
+void arith(hipStream_t s, int type, int op, Opnd a, Opnd b, void *out, int64_t n) {
+    if (n <= 0) return;
+    if (type == QE_DOUBLE) arith_t<double>(s, op, a, b, out, n);
+    else if (type == QE_INT64) arith_t<i64>(s, op, a, b, out, n);
+    else arith_t<int>(s, op, a, b, out, n);
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_neg(const T *a, T *out, i64 n);
+template <> __global__ void __launch_bounds__(256) k_neg<double>(const double *a, double *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = -a[i];   // DNEG
+}
+template <> __global__ void __launch_bounds__(256) k_neg<i64>(const i64 *a, i64 *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (i64)(0ull - (u64)a[i]);
+}
+template <> __global__ void __launch_bounds__(256) k_neg<int>(const int *a, int *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (int)(0u - (u32)a[i]);
+}
+void negate(hipStream_t s, int type, const void *a, void *out, int64_t n) {
+    if (n <= 0) return;
+    const int g = grid_for(n);
+    if (type == QE_DOUBLE) hipLaunchKernelGGL(k_neg<double>, dim3(g), dim3(256), 0, s, (const double *)a, (double *)out, (i64)n);
+    else if (type == QE_INT64) hipLaunchKernelGGL(k_neg<i64>, dim3(g), dim3(256), 0, s, (const i64 *)a, (i64 *)out, (i64)n);
+    else hipLaunchKernelGGL(k_neg<int>, dim3(g), dim3(256), 0, s, (const int *)a, (int *)out, (i64)n);
+}
+
+template <typename F, typename T>
+__global__ void __launch_bounds__(256) k_cast(const F *a, T *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (T)a[i];
+}
+void cast(hipStream_t s, int from, int to, const void *a, void *out, int64_t n) {
+    if (n <= 0) return;
+    const int g = grid_for(n);
+    if (from == QE_INT64 && to == QE_DOUBLE) hipLaunchKernelGGL((k_cast<i64, double>), dim3(g), dim3(256), 0, s, (const i64 *)a, (double *)out, (i64)n);
+    else if (from == QE_INT32 && to == QE_DOUBLE) hipLaunchKernelGGL((k_cast<int, double>), dim3(g), dim3(256), 0, s, (const int *)a, (double *)out, (i64)n);
+    else hipLaunchKernelGGL((k_cast<int, i64>), dim3(g), dim3(256), 0, s, (const int *)a, (i64 *)out, (i64)n);
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_fill(T v, T *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
+}
+void fill(hipStream_t s, int type, Opnd v, void *out, int64_t n) {
+    if (n <= 0) return;
+    const int g = grid_for(n);
+    if (type == QE_DOUBLE) hipLaunchKernelGGL(k_fill<double>, dim3(g), dim3(256), 0, s, v.f, (double *)out, (i64)n);
+    else if (type == QE_INT64) hipLaunchKernelGGL(k_fill<i64>, dim3(g), dim3(256), 0, s, (i64)v.i, (i64 *)out, (i64)n);
+    else hipLaunchKernelGGL(k_fill<int>, dim3(g), dim3(256), 0, s, (int)v.i, (int *)out, (i64)n);
+}
+
+// ---- comparison -> bitmap -----------------------------------------------------------------------------
+__device__ __forceinline__ i64 canon_bits(double d) { return d != d ? 0x7ff8000000000000ll : __builtin_bit_cast(i64, d); }
+__device__ __forceinline__ int dcmp(double a, double b) {   // java.lang.Double.compare
+    if (a < b) return -1;
+    if (a > b) return 1;
+    const i64 x = canon_bits(a), y = canon_bits(b);
+    return x == y ? 0 : (x < y ? -1 : 1);
+}
+
+template <typename T, int CMP, int IEEE> struct CmpOp {
+    static __device__ __forceinline__ bool apply(T a, T b) {
+        if (CMP == C_LT) return a < b;
+        if (CMP == C_LE) return a <= b;
+        if (CMP == C_GE) return a >= b;
+        if (CMP == C_GT) return a > b;
+        if (CMP == C_EQ) return a == b;
+        return a != b;
+    }
+};
+template <int CMP> struct CmpOp<double, CMP, 0> {   // total order: INTERPRETER / BYTECODE_COMPILER
+    static __device__ __forceinline__ bool apply(double a, double b) {
+        if (CMP == C_EQ) return canon_bits(a) == canon_bits(b);
+        if (CMP == C_NE) return canon_bits(a) != canon_bits(b);
+        const int c = dcmp(a, b);
+        if (CMP == C_LT) return c < 0;
+        if (CMP == C_LE) return c <= 0;
+        if (CMP == C_GE) return c >= 0;
+        return c > 0;
+    }
+};
+template <int CMP> struct CmpOp<double, CMP, 1> {   // CLOSURE_COMPILER: IEEE <,<=,>=,>; equals() for ==, !=
+    static __device__ __forceinline__ bool apply(double a, double b) {
+        if (CMP == C_EQ) return canon_bits(a) == canon_bits(b);
+        if (CMP == C_NE) return canon_bits(a) != canon_bits(b);
+        if (CMP == C_LT) return a < b;
+        if (CMP == C_LE) return a <= b;
+        if (CMP == C_GE) return a >= b;
+        return a > b;
+    }
+};
+
+// one thread per row, one wave per 64 rows: the result word IS the __ballot
+template <typename T, int CMP, int IEEE>
+__global__ void __launch_bounds__(256) k_cmp(Ld<T> a, Ld<T> b, u64 *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 padded = (n + 63) & ~63ll;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
+        const bool r = i < n && CmpOp<T, CMP, IEEE>::apply(a[i < n ? i : 0], b[i < n ? i : 0]);
+        const u64 w = __ballot(r);
+        if ((threadIdx.x & 63) == 0) out[i >> 6] = w;
+    }
+}
+
+template <typename T, int IEEE> static void cmp_t(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
+    const int g = grid_for(n);
+    Ld<T> la = mk<T>(a), lb = mk<T>(b);
+    switch (cmp) {
+    case C_LT: hipLaunchKernelGGL((k_cmp<T, C_LT, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_LE: hipLaunchKernelGGL((k_cmp<T, C_LE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_GE: hipLaunchKernelGGL((k_cmp<T, C_GE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_GT: hipLaunchKernelGGL((k_cmp<T, C_GT, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_EQ: hipLaunchKernelGGL((k_cmp<T, C_EQ, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    default: hipLaunchKernelGGL((k_cmp<T, C_NE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    }
+}
+
+void compare(hipStream_t s, int type, int cmp, int ieee, Opnd a, Opnd b, uint64_t *out, int64_t n) {
+    if (n <= 0) return;
+    if (type == QE_DOUBLE) {
+        if (ieee) cmp_t<double, 1>(s, cmp, a, b, (u64 *)out, n);
+        else cmp_t<double, 0>(s, cmp, a, b, (u64 *)out, n);
+    } else if (type == QE_INT64) cmp_t<i64, 0>(s, cmp, a, b, (u64 *)out, n);
+    else cmp_t<int, 0>(s, cmp, a, b, (u64 *)out, n);
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_nonzero(Ld<T> b, u64 *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 padded = (n + 63) & ~63ll;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
+        const bool r = i < n && b[i < n ? i : 0] != 0;
+        const u64 w = __ballot(r);
+        if ((threadIdx.x & 63) == 0) out[i >> 6] = w;
+    }
+}
+void nonzero(hipStream_t s, int type, Opnd b, uint64_t *out, int64_t n) {
+    if (n <= 0) return;
+    const int g = grid_for(n);
+    if (type == QE_INT64) hipLaunchKernelGGL(k_nonzero<i64>, dim3(g), dim3(256), 0, s, mk<i64>(b), (u64 *)out, (i64)n);
+    else hipLaunchKernelGGL(k_nonzero<int>, dim3(g), dim3(256), 0, s, mk<int>(b), (u64 *)out, (i64)n);
+}
+
+// ---- word-parallel logic (64 rows per word) ------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_word_op(int op, const u64 *a, const u64 *b, u64 *out, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) {
+        const u64 x = a[i], y = b[i];
+        u64 r;
+        switch (op) {
+        case W_AND: r = x & y; break;
+        case W_OR: r = x | y; break;
+        case W_XOR: r = x ^ y; break;
+        case W_ANDNOT: r = x & ~y; break;
+        case W_ORNOT: r = x | ~y; break;
+        case W_XNOR: r = ~(x ^ y); break;
+        case W_NOTAND: r = ~x & y; break;
+        default: r = ~x | y; break;
+        }
+        out[i] = r;
+    }
+}
+void word_op(hipStream_t s, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_word_op, dim3(grid_for(nw)), dim3(256), 0, s, op, (const u64 *)a, (const u64 *)b, (u64 *)out, (i64)nw);
+}
+__global__ void __launch_bounds__(256) k_word_not(const u64 *a, u64 *out, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = ~a[i];
+}
+void word_not(hipStream_t s, const uint64_t *a, uint64_t *out, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_word_not, dim3(grid_for(nw)), dim3(256), 0, s, (const u64 *)a, (u64 *)out, (i64)nw);
+}
+__global__ void __launch_bounds__(256) k_word_fill(u64 v, u64 *out, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = v;
+}
+void word_fill(hipStream_t s, uint64_t v, uint64_t *out, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_word_fill, dim3(grid_for(nw)), dim3(256), 0, s, (u64)v, (u64 *)out, (i64)nw);
+}
+
+// Kleene three-valued AND / OR (Interpreter.kt:54-91; SURVEY 2.1 word-parallel form)
+__global__ void __launch_bounds__(256) k_kleene(int is_and, const u64 *va, const u64 *ka, const u64 *vb, const u64 *kb,
+                                                u64 *vout, u64 *kout, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) {
+        const u64 xa = ka ? ka[i] : ~0ull, xb = kb ? kb[i] : ~0ull;
+        const u64 a = va[i] & xa, b = vb[i] & xb;   // value bits under a null are 0
+        u64 v, k;
+        if (is_and) {
+            v = a & b;
+            k = (xa & xb) | (xa & ~a) | (xb & ~b);   // false dominates null
+        } else {
+            v = a | b;
+            k = (xa & xb) | a | b;                   // true dominates null
+        }
+        vout[i] = v;
+        if (kout) kout[i] = k;
+    }
+}
+void kleene(hipStream_t s, bool is_and, const uint64_t *va, const uint64_t *ka, const uint64_t *vb, const uint64_t *kb,
+            uint64_t *vout, uint64_t *kout, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_kleene, dim3(grid_for(nw)), dim3(256), 0, s, is_and ? 1 : 0, (const u64 *)va, (const u64 *)ka,
+                       (const u64 *)vb, (const u64 *)kb, (u64 *)vout, (u64 *)kout, (i64)nw);
+}
+
+// ---- IF -----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_select(const u64 *cond, Ld<T> t, Ld<T> e, T *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool c = (cond[i >> 6] >> (i & 63)) & 1ull;
+        out[i] = c ? t[i] : e[i];
+    }
+}
+void select(hipStream_t s, int type, const uint64_t *cond, Opnd t, Opnd e, void *out, int64_t n) {
+    if (n <= 0) return;
+    const int g = grid_for(n);
+    if (type == QE_DOUBLE) hipLaunchKernelGGL(k_select<double>, dim3(g), dim3(256), 0, s, (const u64 *)cond, mk<double>(t), mk<double>(e), (double *)out, (i64)n);
+    else if (type == QE_INT64) hipLaunchKernelGGL(k_select<i64>, dim3(g), dim3(256), 0, s, (const u64 *)cond, mk<i64>(t), mk<i64>(e), (i64 *)out, (i64)n);
+    else hipLaunchKernelGGL(k_select<int>, dim3(g), dim3(256), 0, s, (const u64 *)cond, mk<int>(t), mk<int>(e), (int *)out, (i64)n);
+}
+__global__ void __launch_bounds__(256) k_select_words(const u64 *c, const u64 *t, const u64 *e, u64 *out, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = (c[i] & t[i]) | (~c[i] & e[i]);
+}
+void select_words(hipStream_t s, const uint64_t *c, const uint64_t *t, const uint64_t *e, uint64_t *out, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_select_words, dim3(grid_for(nw)), dim3(256), 0, s, (const u64 *)c, (const u64 *)t, (const u64 *)e, (u64 *)out, (i64)nw);
+}
+
+// ---- filter: bitmap -> ascending row ids (stable) -------------------------------------------------------------
+__device__ __forceinline__ u64 keep_word(const u64 *v, const u64 *k, i64 w, i64 n) {
+    u64 x = v[w];
+    if (k) x &= k[w];                               // FilterOperator.kt:20: non-null AND true
+    const i64 rem = n - w * 64;
+    if (rem < 64) x &= (1ull << rem) - 1ull;        // bits past the last row
+    return x;
+}
+__global__ void __launch_bounds__(256) k_word_popcounts(const u64 *v, const u64 *k, i64 n, u32 *counts, i64 nw) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) counts[w] = (u32)__popcll(keep_word(v, k, w, n));
+}
+void word_popcounts(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t n, uint32_t *counts, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_word_popcounts, dim3(grid_for(nw)), dim3(256), 0, s, (const u64 *)v, (const u64 *)k, (i64)n, counts, (i64)nw);
+}
+
+// exclusive scan of u32 counts in three passes: block sums (1024 per block), scan of the block sums by ONE
+// workgroup, per-block scan with offset.  Wave-level scans use DPP-free shuffles; 16 waves per block.
+__device__ __forceinline__ u32 wave_incl_scan(u32 x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+__device__ __forceinline__ u32 block_excl_scan_1024(u32 x, u32 *lds, u32 &block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 incl = wave_incl_scan(x, lane);
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const u32 t = lane < 16 ? lds[lane] : 0u;
+        const u32 ti = wave_incl_scan(t, lane);
+        if (lane < 16) lds[16 + lane] = ti - t;
+        if (lane == 15) lds[32] = ti;
+    }
+    __syncthreads();
+    block_total = lds[32];
+    const u32 r = lds[16 + wave] + incl - x;
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(1024) k_scan_block_sums(const u32 *in, u32 *block_sums, i64 n) {
+    __shared__ u32 lds[40];
+    const i64 i = (i64)blockIdx.x * 1024 + threadIdx.x;
+    u32 total;
+    (void)block_excl_scan_1024(i < n ? in[i] : 0u, lds, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) k_scan_of_sums(u32 *block_sums, i64 nblocks, u64 *total_out) {
+    __shared__ u32 lds[40];
+    u64 carry = 0;
+    for (i64 base = 0; base < nblocks; base += 1024) {
+        const i64 i = base + threadIdx.x;
+        const u32 x = i < nblocks ? block_sums[i] : 0u;
+        u32 total;
+        const u32 e = block_excl_scan_1024(x, lds, total);
+        if (i < nblocks) block_sums[i] = (u32)(carry + e);
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(1024) k_scan_final(const u32 *in, const u32 *block_offsets, u32 *out, i64 n) {
+    __shared__ u32 lds[40];
+    const i64 i = (i64)blockIdx.x * 1024 + threadIdx.x;
+    u32 total;
+    const u32 e = block_excl_scan_1024(i < n ? in[i] : 0u, lds, total);
+    if (i < n) out[i] = block_offsets[blockIdx.x] + e;
+}
+void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint32_t *block_sums, int64_t n,
+                        unsigned long long *total) {
+    if (n <= 0) return;
+    const int64_t nblocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblocks), dim3(1024), 0, s, in, block_sums, (i64)n);
+    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, s, block_sums, (i64)nblocks, (u64 *)total);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks), dim3(1024), 0, s, in, block_sums, out, (i64)n);
+}
+
+// one wave per bitmap word: lane l emits row 64*w + l at offset[w] + popcount(bits below l)
+__global__ void __launch_bounds__(256) k_expand_indices(const u64 *v, const u64 *k, i64 n, const u32 *word_offsets,
+                                                        u32 *indices, i64 nw) {
+    const int lane = threadIdx.x & 63;
+    const i64 wstride = (i64)gridDim.x * (blockDim.x >> 6);
+    for (i64 w = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nw; w += wstride) {
+        const u64 x = keep_word(v, k, w, n);
+        if ((x >> lane) & 1ull) {
+            const u32 below = (u32)__popcll(x & ((1ull << lane) - 1ull));
+            indices[word_offsets[w] + below] = (u32)(w * 64 + lane);
+        }
+    }
+}
+void expand_indices(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t n, const uint32_t *word_offsets,
+                    uint32_t *indices, int64_t nw) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_expand_indices, dim3(grid_for(nw, 4)), dim3(256), 0, s, (const u64 *)v, (const u64 *)k, (i64)n,
+                       word_offsets, indices, (i64)nw);
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_gather(const T *src, const u32 *idx, T *out, i64 m) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) out[j] = src[idx[j]];
+}
+void gather(hipStream_t s, int type, const void *src, const uint32_t *idx, void *out, int64_t m) {
+    if (m <= 0) return;
+    const int g = grid_for(m);
+    if (type == QE_DOUBLE || type == QE_INT64) hipLaunchKernelGGL(k_gather<u64>, dim3(g), dim3(256), 0, s, (const u64 *)src, idx, (u64 *)out, (i64)m);
+    else hipLaunchKernelGGL(k_gather<u32>, dim3(g), dim3(256), 0, s, (const u32 *)src, idx, (u32 *)out, (i64)m);
+}
+__global__ void __launch_bounds__(256) k_gather_bits(const u64 *src, const u32 *idx, u64 *out, i64 m) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    const i64 padded = (m + 63) & ~63ll;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < padded; j += stride) {
+        bool b = false;
+        if (j < m) {
+            const u32 r = idx[j];
+            b = (src[r >> 6] >> (r & 63)) & 1ull;
+        }
+        const u64 w = __ballot(b);
+        if ((threadIdx.x & 63) == 0) out[j >> 6] = w;
+    }
+}
+void gather_bits(hipStream_t s, const uint64_t *src, const uint32_t *idx, uint64_t *out, int64_t m) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_gather_bits, dim3(grid_for(m)), dim3(256), 0, s, (const u64 *)src, idx, (u64 *)out, (i64)m);
+}
+
+}  // namespace pn
+}  // namespace qe

@@ -35,3 +35,19 @@ def gpu_ctx(native_lib):
     ctx = engine.Context(device=0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_per_node(native_lib):
+    """Same device, kernel-per-expression-node executor (QE_EXEC_PER_NODE)."""
+    from queryengine_amd import engine, native
+    ctx = engine.Context(device=0, exec_mode=native.EXEC_PER_NODE)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(params=["fused", "per_node"])
+def any_ctx(request, gpu_ctx, gpu_ctx_per_node):
+    """Every parity test runs through BOTH execution modes, like the reference's
+    @EnumSource(Mode::class) tests run through all three evaluators (CompilerTest.kt:13)."""
+    return gpu_ctx if request.param == "fused" else gpu_ctx_per_node

@@ -35,48 +35,48 @@ def run_both(ctx, oracle, cols, flt, projs, mode=None):
     return got
 
 
-def test_config1_a_plus_b_where_a_lt_100(gpu_ctx, oracle):
+def test_config1_a_plus_b_where_a_lt_100(any_ctx, oracle):
     """BASELINE config 1: SELECT a + b FROM t WHERE a < 100 (reference types: DOUBLE)."""
     rng = np.random.default_rng(1)
     n = 100_000
     a = Column(D, rng.integers(0, 1000, n).astype(np.float64))
     b = Column(D, rng.integers(0, 2 ** 31, n).astype(np.float64))
-    got = run_both(gpu_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(100)),
+    got = run_both(any_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(100)),
                    [fn(Fn.ADD, col("a", 0, D), col("b", 1, D))])
     assert 0.05 * n < len(got[0]) < 0.15 * n
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 127, 128, 129, 511, 512, 513, 16383, 16384, 16385, 70001, 200_000])
-def test_ragged_sizes(gpu_ctx, oracle, n):
+def test_ragged_sizes(any_ctx, oracle, n):
     """empty / ragged inputs around the 64-row bitmap word and the tile size"""
     rng = np.random.default_rng(n)
     a = random_column(rng, I64, n, special=False)
     c = random_column(rng, D, n, null_frac=0.2 if n else 0.0)
     flt = fn(Fn.AND, fn(Fn.CMP_LT, col("a", 0, I64), num(100)), fn(Fn.CMP_LT, col("c", 1, D), num(0.5)))
-    run_both(gpu_ctx, oracle, [a, c], flt, [fn(Fn.ADD, col("a", 0, I64), col("a", 0, I64)),
+    run_both(any_ctx, oracle, [a, c], flt, [fn(Fn.ADD, col("a", 0, I64), col("a", 0, I64)),
                                             fn(Fn.MUL, col("c", 1, D), num(2.0))])
 
 
 @pytest.mark.parametrize("sel", [0.0, 0.01, 0.5, 1.0])
-def test_selectivity_extremes(gpu_ctx, oracle, sel):
+def test_selectivity_extremes(any_ctx, oracle, sel):
     rng = np.random.default_rng(7)
     n = 50_000
     a = Column(D, rng.random(n))
     b = random_column(rng, I64, n)
-    run_both(gpu_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(sel)),
+    run_both(any_ctx, oracle, [a, b], fn(Fn.CMP_LT, col("a", 0, D), num(sel)),
              [col("b", 1, I64), fn(Fn.SUB, col("a", 0, D), num(1.0))])
 
 
-def test_no_filter_projection_only(gpu_ctx, oracle):
+def test_no_filter_projection_only(any_ctx, oracle):
     rng = np.random.default_rng(3)
     n = 10_000
     cols = [random_column(rng, D, n, null_frac=0.1), random_column(rng, D, n)]
-    run_both(gpu_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), col("b", 1, D)),
+    run_both(any_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), col("b", 1, D)),
                                            fn(Fn.DIV, col("a", 0, D), col("b", 1, D)),
                                            fn(Fn.MOD, col("a", 0, D), col("b", 1, D))])
 
 
-def test_kleene_tables_with_null_columns(gpu_ctx, oracle):
+def test_kleene_tables_with_null_columns(any_ctx, oracle):
     """AND / OR / NOT / IF over nullable BOOLEAN columns (CompilerTest.kt:55-65,81-91,107-111 as columns)."""
     vals = [True, False, None]
     p = Column.from_values(B, [x for x in vals for _ in vals] * 50)
@@ -85,17 +85,17 @@ def test_kleene_tables_with_null_columns(gpu_ctx, oracle):
     projs = [fn(Fn.AND, P, Q), fn(Fn.OR, P, Q), fn(Fn.NOT, P),
              fn(Fn.IF, P, StringLiteralExpression("t"), StringLiteralExpression("f")),
              fn(Fn.IF, P, Q, fn(Fn.NOT, Q)), fn(Fn.CMP_EQ, P, Q), fn(Fn.CMP_LT, P, Q)]
-    got = run_both(gpu_ctx, oracle, [p, q], None, projs)
+    got = run_both(any_ctx, oracle, [p, q], None, projs)
     assert got[0].to_list()[:9] == [True, False, None, False, False, False, None, False, None]
     assert got[1].to_list()[:9] == [True, True, True, True, False, None, True, None, None]
     assert got[3].to_list()[:9] == ["t", "t", "t", "f", "f", "f", None, None, None]
     # filter keeps only non-null true (FilterOperator.kt:20)
-    kept = run_both(gpu_ctx, oracle, [p, q], fn(Fn.OR, P, Q), [P, Q])
+    kept = run_both(any_ctx, oracle, [p, q], fn(Fn.OR, P, Q), [P, Q])
     assert len(kept[0]) == 50 * 5
 
 
 @pytest.mark.parametrize("mode_name", ["total", "ieee"])
-def test_f64_special_values_all_comparisons(gpu_ctx, oracle, mode_name):
+def test_f64_special_values_all_comparisons(any_ctx, oracle, mode_name):
     """NaN / -0.0 / Inf cross product, both comparison semantics."""
     from helpers import SPECIAL_F64
     xs = [x for x in SPECIAL_F64 for _ in SPECIAL_F64]
@@ -106,27 +106,27 @@ def test_f64_special_values_all_comparisons(gpu_ctx, oracle, mode_name):
     projs += [fn(f, A_, B_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)] + [fn(Fn.UNARY_MINUS, A_)]
     projs += [fn(Fn.CMP_LT, A_, num(0.0)), fn(Fn.CMP_GE, A_, num(float("nan"))), fn(Fn.CMP_GT, A_, num(100.0))]
     if mode_name == "total":
-        gpu_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
-        run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.BYTECODE_COMPILER)
-        run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.INTERPRETER)
+        any_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
+        run_both(any_ctx, oracle, [a, b], None, projs, oracle.BYTECODE_COMPILER)
+        run_both(any_ctx, oracle, [a, b], None, projs, oracle.INTERPRETER)
     else:
-        gpu_ctx.set_cmp_semantics(N.CMP_IEEE)
+        any_ctx.set_cmp_semantics(N.CMP_IEEE)
         try:
-            run_both(gpu_ctx, oracle, [a, b], None, projs, oracle.CLOSURE_COMPILER)
+            run_both(any_ctx, oracle, [a, b], None, projs, oracle.CLOSURE_COMPILER)
         finally:
-            gpu_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
+            any_ctx.set_cmp_semantics(N.CMP_TOTAL_ORDER)
 
 
-def test_fma_contraction_is_off(gpu_ctx, oracle):
+def test_fma_contraction_is_off(any_ctx, oracle):
     """a + 10*b must round twice like DMUL;DADD."""
     a = float.fromhex("0x1.acd7053aa42a3p-1")
     b = float.fromhex("0x1.1ce794bb05232p-1")
     cols = [Column(D, np.full(300, a)), Column(D, np.full(300, b))]
-    got = run_both(gpu_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), fn(Fn.MUL, num(10.0), col("b", 1, D)))])
+    got = run_both(any_ctx, oracle, cols, None, [fn(Fn.ADD, col("a", 0, D), fn(Fn.MUL, num(10.0), col("b", 1, D)))])
     assert got[0].data[0].hex() == "0x1.99bc5a911af12p+2"
 
 
-def test_integer_extension_wrap_div_mod(gpu_ctx, oracle):
+def test_integer_extension_wrap_div_mod(any_ctx, oracle):
     from helpers import SPECIAL_I32, SPECIAL_I64
     xs = [x for x in SPECIAL_I64 for _ in SPECIAL_I64]
     ys = [y for _ in SPECIAL_I64 for y in SPECIAL_I64]
@@ -139,27 +139,27 @@ def test_integer_extension_wrap_div_mod(gpu_ctx, oracle):
     A_, B_, C_, D_ = col("a", 0, I64), col("b", 1, I64), col("c", 2, I32), col("d", 3, I32)
     projs = [fn(f, A_, B_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)]
     projs += [fn(f, C_, D_) for f in (Fn.ADD, Fn.SUB, Fn.MUL, Fn.DIV, Fn.MOD)]
-    run_both(gpu_ctx, oracle, cols, None, projs)
+    run_both(any_ctx, oracle, cols, None, projs)
     projs = [fn(Fn.ADD, A_, C_), fn(Fn.MUL, C_, num(1.5)), fn(Fn.UNARY_MINUS, A_), fn(Fn.UNARY_MINUS, C_),
               fn(Fn.CMP_LT, A_, B_), fn(Fn.CMP_EQ, A_, C_), fn(Fn.CMP_GE, C_, num(100.0)), fn(Fn.CMP_LE, A_, num(99.5))]
-    run_both(gpu_ctx, oracle, cols, None, projs)
+    run_both(any_ctx, oracle, cols, None, projs)
 
 
-def test_integers_within_2_53_match_double_only_reference(gpu_ctx, oracle):
+def test_integers_within_2_53_match_double_only_reference(any_ctx, oracle):
     """with |values| <= 2^53 the INT64 extension equals the DOUBLE-only reference."""
     rng = np.random.default_rng(11)
     n = 20_000
     ai = rng.integers(0, 1000, n, dtype=np.int64)
     bi = rng.integers(0, 2 ** 31, n, dtype=np.int64)
     flt_i = fn(Fn.CMP_LT, col("a", 0, I64), num(100))
-    got = run_both(gpu_ctx, oracle, [Column(I64, ai), Column(I64, bi)], flt_i, [fn(Fn.ADD, col("a", 0, I64), col("b", 1, I64))])
+    got = run_both(any_ctx, oracle, [Column(I64, ai), Column(I64, bi)], flt_i, [fn(Fn.ADD, col("a", 0, I64), col("b", 1, I64))])
     ref = oracle.filter_project([Column(D, ai.astype(np.float64)), Column(D, bi.astype(np.float64))],
                                 fn(Fn.CMP_LT, col("a", 0, D), num(100)), [fn(Fn.ADD, col("a", 0, D), col("b", 1, D))],
                                 oracle.BYTECODE_COMPILER)
     assert np.array_equal(got[0].data.astype(np.float64), ref[0].data)
 
 
-def test_dictionary_equality_and_gather_project(gpu_ctx, oracle):
+def test_dictionary_equality_and_gather_project(any_ctx, oracle):
     """BASELINE config 4 shape: SELECT s, v FROM t WHERE s = 'k0042'"""
     rng = np.random.default_rng(5)
     n = 40_000
@@ -167,17 +167,17 @@ def test_dictionary_equality_and_gather_project(gpu_ctx, oracle):
     s = random_column(rng, S, n, null_frac=0.05, dictionary=d)
     v = Column(D, rng.random(n))
     Sx, V = col("s", 0, S), col("v", 1, D)
-    got = run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("k0042")), [Sx, V])
+    got = run_both(any_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("k0042")), [Sx, V])
     assert set(got[0].to_list()) <= {"k0042"}
-    run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_NE, Sx, StringLiteralExpression("nope")), [Sx])
-    run_both(gpu_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("nope")), [Sx, V])
-    run_both(gpu_ctx, oracle, [s, v], None,
+    run_both(any_ctx, oracle, [s, v], fn(Fn.CMP_NE, Sx, StringLiteralExpression("nope")), [Sx])
+    run_both(any_ctx, oracle, [s, v], fn(Fn.CMP_EQ, Sx, StringLiteralExpression("nope")), [Sx, V])
+    run_both(any_ctx, oracle, [s, v], None,
              [fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), Sx, StringLiteralExpression("other")),
               fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), StringLiteralExpression("k0001"), Sx),
               fn(Fn.CMP_EQ, Sx, Sx)])
 
 
-def test_q6_shape(gpu_ctx, oracle):
+def test_q6_shape(any_ctx, oracle):
     """BASELINE config 3 shape: TPC-H Q6 predicate, int32 dates, f64 price/discount/quantity."""
     rng = np.random.default_rng(6)
     n = 60_000
@@ -188,12 +188,12 @@ def test_q6_shape(gpu_ctx, oracle):
     SH, DI, QT, PR = col("l_shipdate", 0, I32), col("l_discount", 1, D), col("l_quantity", 2, D), col("l_extendedprice", 3, D)
     flt = fn(Fn.AND, fn(Fn.AND, fn(Fn.AND, fn(Fn.AND, fn(Fn.CMP_GE, SH, num(8766)), fn(Fn.CMP_LT, SH, num(9131))),
                                    fn(Fn.CMP_GE, DI, num(0.05))), fn(Fn.CMP_LE, DI, num(0.07))), fn(Fn.CMP_LT, QT, num(24)))
-    got = run_both(gpu_ctx, oracle, [ship, disc, qty, price], flt, [fn(Fn.MUL, PR, DI)])
+    got = run_both(any_ctx, oracle, [ship, disc, qty, price], flt, [fn(Fn.MUL, PR, DI)])
     assert 0 < len(got[0]) < n * 0.05
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_expression_trees(gpu_ctx, oracle, seed):
+def test_random_expression_trees(any_ctx, oracle, seed):
     """Differential test in the spirit of CompilerTest's @EnumSource(Mode): random typed trees,
     null-heavy data with NaN/-0.0/extreme integers, GPU vs oracle."""
     rnd = random.Random(seed)
@@ -207,7 +207,7 @@ def test_random_expression_trees(gpu_ctx, oracle, seed):
     for _ in range(4):
         flt = g.boolean(3) if rnd.random() < 0.8 else None
         projs = [g.numeric(3) if rnd.random() < 0.7 else g.boolean(2) for _ in range(rnd.randint(1, 3))]
-        run_both(gpu_ctx, oracle, cols, flt, projs)
+        run_both(any_ctx, oracle, cols, flt, projs)
 
 
 def test_generator_matches_oracle(gpu_ctx, oracle):
