@@ -458,12 +458,16 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     FusedGeometry g;
     const int t = ctx->opts.tuning[0], u = ctx->opts.tuning[1];
     if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) g.threads = t;
+    const int mw = ctx->opts.tuning[3] / 100;    // tuning[3] = 100 * min_waves + blocks_per_cu
+    if (mw >= 1 && mw <= 8) g.min_waves = mw;
     if (u >= 1 && u <= 16) g.unroll = u;
     const int spc = ctx->opts.tuning[4];
     if (spc >= 16 && spc <= 4096) g.subs_per_chunk = (spc + 15) & ~15;
     const int lbk = ctx->opts.tuning[6];
     if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
-    if (ctx->opts.tuning[7] == 2) g.stagger = 0;
+    const int st7 = ctx->opts.tuning[7];
+    if (st7 == 2) g.stagger = 0;
+    if (st7 >= 10) g.resolve_at = st7 - 10;   // 10 + n: resolve n sub-tiles into the next chunk
     return g;
 }
 
@@ -486,7 +490,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -504,6 +508,34 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
     auto plan = std::make_shared<Plan>();
     plan->cg = generate_fused_source(in);
+    if (ctx->opts.tuning[3] / 100 == 0) {
+        // Register budget: per lane a sub-tile holds 2*U rows of every input column, later of every output
+        // column (inputs die as outputs are produced), plus one VGPR per boolean (keep / validity) per row.
+        // Pick the __launch_bounds__ occupancy the estimate allows instead of forcing spills; shrink the
+        // sub-tile for very wide plans.
+        auto dwords = [](int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 2 : 1; };
+        for (;;) {
+            int in_dw = 0, out_dw = 0, nbool = 1;
+            for (int c : plan->cg.used_cols) {
+                in_dw += dwords(in.schema[c].type);
+                nbool += in.schema[c].nullable ? 1 : 0;
+            }
+            for (const OutSpec &o : plan->cg.outs) {
+                out_dw += dwords(o.type);
+                nbool += o.nullable ? 1 : 0;
+            }
+            const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 30;
+            const int mw = est <= 128 ? 4 : est <= 168 ? 3 : est <= 256 ? 2 : 1;
+            if (est > 256 && in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
+                in.geo.unroll /= 2;
+                in.geo.subs_per_chunk *= 2;   // keep the chunk size
+                continue;
+            }
+            if (mw != in.geo.min_waves) in.geo.min_waves = mw;
+            break;
+        }
+        plan->cg = generate_fused_source(in);
+    }
     plan->geo = in.geo;
     plan->aggregate = agg_fns != nullptr;
     plan->kernel = ctx->jit->get(plan->cg.source, "qe_fused", load);
@@ -518,7 +550,7 @@ int device_cus(int device) {
 }
 
 int blocks_per_cu(const qe_ctx *ctx, const Plan &plan) {
-    if (ctx->opts.tuning[3] > 0) return ctx->opts.tuning[3];
+    if (ctx->opts.tuning[3] % 100 > 0) return ctx->opts.tuning[3] % 100;
     int nb = 0;
     hipError_t e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, plan.kernel.fn, plan.geo.threads, 0);
     if (e != hipSuccess) {

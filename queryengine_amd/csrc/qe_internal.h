@@ -149,8 +149,10 @@ struct FusedGeometry {
     int rows_per_lane = 2;
     int unroll = 8;          // load groups (of 128 rows) per sub-tile
     int subs_per_chunk = 16; // sub-tiles per chunk (one ticket + one look-back per chunk); multiple of 16
-    int lookback_k = 8;      // descriptor windows (of 64) loaded per look-back round
+    int lookback_k = 4;      // descriptor windows (of 64) loaded per look-back round
     int stagger = 1;         // grade the sizes of the first chunks
+    int min_waves = 4;       // __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow
+    int resolve_at = 1;      // sub-tiles into the next chunk from which the previous chunk's resolve is tried
     int sub_rows() const { return 64 * rows_per_lane * unroll; }
     int chunk_rows() const { return sub_rows() * subs_per_chunk; }
 };

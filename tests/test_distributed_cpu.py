@@ -1,0 +1,103 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Each rank owns a contiguous row-range shard, computes its
+local filter+project result (here with the oracle standing in for the GPU, which is absent), and the
+exchange step (count all-gather + grouped point-to-point gatherv) must reproduce, on rank 0, exactly
+the single-process result in input order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nrows, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import qe_oracle as O
+        from queryengine_amd import workloads as W
+        from queryengine_amd.distributed import gatherv, shard_range
+        from queryengine_amd.table import Column
+        wl = W.config2(nrows, null_pct=1)
+        begin, end = shard_range(nrows, rank, world)
+        cols = []
+        for c in wl.columns:
+            s = O.GenSpec()
+            s.kind, s.col_id, s.modulus, s.offset, s.step, s.aux_col_id, s.null_pct = \
+                c.kind, c.col_id, c.modulus, c.offset, c.step, c.aux_col_id, c.null_pct
+            data, valid = O.generate(s, 42, begin, end - begin, np.float64 if c.type.name == "DOUBLE" else np.int64)
+            cols.append(Column(c.type, data, valid))
+        local = O.filter_project(cols, wl.filter, wl.projections, O.BYTECODE_COMPILER)
+        gathered = []
+        for col in local:
+            g = gatherv(torch.from_numpy(col.data.copy()), 0)
+            valid = col.valid if col.valid is not None else np.ones(len(col), dtype=bool)
+            gv = gatherv(torch.from_numpy(valid.astype(np.uint8)), 0)
+            gathered.append((g, gv))
+        # an empty shard and an uneven split must work too
+        e = gatherv(torch.arange(3 if rank == 1 else 0, dtype=torch.int64), 0)
+        if rank == 0:
+            q.put(([(g.numpy(), gv.numpy()) for g, gv in gathered], e.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_are_contiguous_aligned_and_cover():
+    sys.path.insert(0, ROOT)
+    from queryengine_amd.distributed import shard_range
+    for n in (0, 1, 63, 64, 1000, 10 ** 9 + 7, 10 ** 10):
+        for world in (1, 2, 4, 8):
+            prev = 0
+            for r in range(world):
+                b, e = shard_range(n, r, world)
+                assert b == prev and e >= b and (b % 64 == 0 or b == n)
+                prev = e
+            assert prev == n
+
+
+@pytest.mark.timeout(300)
+def test_sharded_filter_project_gather_matches_single_process(oracle):
+    world, nrows = 2, 20_000
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nrows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, empty_case = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from queryengine_amd import workloads as W
+    from queryengine_amd.table import Column
+    wl = W.config2(nrows, null_pct=1)
+    cols = []
+    for c in wl.columns:
+        s = oracle.GenSpec()
+        s.kind, s.col_id, s.modulus, s.offset, s.step, s.aux_col_id, s.null_pct = \
+            c.kind, c.col_id, c.modulus, c.offset, c.step, c.aux_col_id, c.null_pct
+        data, valid = oracle.generate(s, 42, 0, nrows, np.float64 if c.type.name == "DOUBLE" else np.int64)
+        cols.append(Column(c.type, data, valid))
+    want = oracle.filter_project(cols, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+    assert len(want[0]) > 0
+    for (g, gv), w in zip(got, want):
+        wv = w.valid if w.valid is not None else np.ones(len(w), dtype=bool)
+        assert np.array_equal(gv.astype(bool), wv)
+        assert np.array_equal(g[wv].view(np.uint64), w.data[wv].view(np.uint64))
+    assert np.array_equal(empty_case, np.arange(3))
