@@ -207,6 +207,10 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
                             const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg,
                             double *out_values, uint8_t *out_valid, int64_t *out_selected_rows);
 
+/* plan-time preparation of the aggregate plan (JIT compile + cache), no execution */
+int32_t qe_filter_aggregate_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                    const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg);
+
 /* ---- results --------------------------------------------------------------------------- */
 typedef struct {
     int32_t type;

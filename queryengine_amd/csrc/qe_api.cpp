@@ -509,10 +509,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     auto plan = std::make_shared<Plan>();
     plan->cg = generate_fused_source(in);
     if (ctx->opts.tuning[3] / 100 == 0) {
-        // Register budget: per lane a sub-tile holds 2*U rows of every input column, later of every output
-        // column (inputs die as outputs are produced), plus one VGPR per boolean (keep / validity) per row.
-        // Pick the __launch_bounds__ occupancy the estimate allows instead of forcing spills; shrink the
-        // sub-tile for very wide plans.
+        // Register budget.  Per lane a sub-tile holds 2*U rows of every input column, later of every output
+        // column, plus one VGPR per boolean per row: shrink the sub-tile of very wide plans first.  Then ask
+        // for the highest occupancy (__launch_bounds__ waves per SIMD) that compiles WITHOUT SCRATCH: a spill
+        // turns into HBM traffic (84 B/lane of scratch cost 2.7 GB of extra writes per 1 B rows when measured).
         auto dwords = [](int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 2 : 1; };
         for (;;) {
             int in_dw = 0, out_dw = 0, nbool = 1;
@@ -524,17 +524,32 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
                 out_dw += dwords(o.type);
                 nbool += o.nullable ? 1 : 0;
             }
-            const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 30;
-            const int mw = est <= 128 ? 4 : est <= 168 ? 3 : est <= 256 ? 2 : 1;
-            if (est > 256 && in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
+            const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 54;
+            if (est > 300 && in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
                 in.geo.unroll /= 2;
                 in.geo.subs_per_chunk *= 2;   // keep the chunk size
+                plan->cg = generate_fused_source(in);
                 continue;
             }
-            if (mw != in.geo.min_waves) in.geo.min_waves = mw;
+            in.geo.min_waves = est <= 128 ? 4 : est <= 168 ? 3 : est <= 256 ? 2 : 1;
             break;
         }
-        plan->cg = generate_fused_source(in);
+        for (;;) {
+            plan->cg = generate_fused_source(in);
+            plan->kernel = ctx->jit->get(plan->cg.source, "qe_fused", false);   // compile (or cache hit) only
+            if (ctx->jit->last_scratch <= 0) break;
+            if (in.geo.min_waves > 2) {
+                in.geo.min_waves--;
+            } else if (in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
+                in.geo.unroll /= 2;            // a smaller sub-tile rather than one wave per SIMD
+                in.geo.subs_per_chunk *= 2;
+                in.geo.min_waves = 3;
+            } else if (in.geo.min_waves > 1) {
+                in.geo.min_waves--;
+            } else {
+                break;
+            }
+        }
     }
     plan->geo = in.geo;
     plan->aggregate = agg_fns != nullptr;
@@ -675,10 +690,10 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         for (size_t i = 0; i < res->cols.size(); i++) {
             const OutColumn &oc = res->cols[i];
             const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);
-            p.stage[i] = ctx->pool.alloc(slots * (size_t)chunk_rows * w);
+            p.stage[i] = ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows() * w);
             scratch.push_back(p.stage[i]);
             if (oc.nullable) {
-                p.stagevalid[i] = (unsigned char *)ctx->pool.alloc(slots * (size_t)chunk_rows);
+                p.stagevalid[i] = (unsigned char *)ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows());
                 scratch.push_back(p.stagevalid[i]);
             }
         }
@@ -767,6 +782,15 @@ int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_ex
         auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false);
         ctx->source_scratch = plan->cg.source;
         *out = ctx->source_scratch.c_str();
+    });
+}
+
+int32_t qe_filter_aggregate_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                    const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg) {
+    if (!ctx || !batch || nagg <= 0 || !exprs || !agg_fns) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        if (ctx->device >= 0) need_device(ctx);
+        (void)get_plan(ctx, batch, filter, exprs, nagg, agg_fns, ctx->device >= 0);
     });
 }
 

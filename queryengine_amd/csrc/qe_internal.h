@@ -155,6 +155,10 @@ struct FusedGeometry {
     int resolve_at = 1;      // sub-tiles into the next chunk from which the previous chunk's resolve is tried
     int sub_rows() const { return 64 * rows_per_lane * unroll; }
     int chunk_rows() const { return sub_rows() * subs_per_chunk; }
+    // rows per staging slot: the chunk plus an odd multiple of 64 rows, so that slot bases do not all
+    // alias onto the same HBM channels (a power-of-two slot stride made every slot's small used prefix hit
+    // the same few channels)
+    int slot_rows() const { return chunk_rows() + 832; }
 };
 
 struct CodegenInput {
@@ -180,6 +184,7 @@ CodegenOutput generate_fused_source(const CodegenInput &in);
 struct Kernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    int scratch = -1;   // spill bytes per lane (-1 unknown)
 };
 
 class Jit {
@@ -189,7 +194,8 @@ public:
     // compile (or fetch from memory / disk cache) and load; needs a current device unless load == false
     Kernel get(const std::string &source, const char *entry, bool load = true);
     static std::vector<char> compile(const std::string &source);
-    int compiles = 0, disk_hits = 0, mem_hits = 0;
+    static int scratch_bytes(const std::vector<char> &code);
+    int compiles = 0, disk_hits = 0, mem_hits = 0, last_scratch = -1;
 
 private:
     std::string cache_dir_;

@@ -51,12 +51,30 @@ std::vector<char> Jit::compile(const std::string &source) {
     return code;
 }
 
+// Scratch (register spill) bytes per lane of the first kernel of a code object: the msgpack metadata
+// note carries ".private_segment_fixed_size" followed by a small unsigned integer.
+int Jit::scratch_bytes(const std::vector<char> &code) {
+    static const char key[] = ".private_segment_fixed_size";
+    const size_t kl = sizeof(key) - 1;
+    for (size_t i = 0; i + kl + 5 < code.size(); i++) {
+        if (std::memcmp(code.data() + i, key, kl) != 0) continue;
+        const unsigned char *p = (const unsigned char *)code.data() + i + kl;
+        if (p[0] < 0x80) return p[0];
+        if (p[0] == 0xcc) return p[1];
+        if (p[0] == 0xcd) return (p[1] << 8) | p[2];
+        if (p[0] == 0xce) return (int)(((unsigned)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]);
+        return -1;
+    }
+    return -1;
+}
+
 Kernel Jit::get(const std::string &source, const char *entry, bool load) {
     char key[64];
     std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source), source.size(), kArch);
     auto it = loaded_.find(key);
     if (it != loaded_.end()) {
         mem_hits++;
+        last_scratch = it->second.scratch;
         return it->second;
     }
     std::vector<char> code;
@@ -86,6 +104,8 @@ Kernel Jit::get(const std::string &source, const char *entry, bool load) {
         }
     }
     Kernel k;
+    k.scratch = scratch_bytes(code);
+    last_scratch = k.scratch;
     if (!load) return k;
     QE_HIP(hipModuleLoadData(&k.module, code.data()));
     QE_HIP(hipModuleGetFunction(&k.fn, k.module, entry));

@@ -322,3 +322,10 @@ def filter_aggregate(ctx: Context, batch: DeviceBatch, filter: Optional[Compiled
     N.check(ctx.handle, ctx._lib.qe_filter_aggregate(ctx.handle, batch.handle, filter.handle if filter else None,
                                                      _expr_array(exprs), fns, n, vals, valid, C.byref(nsel)))
     return [float(vals[i]) if valid[i] else None for i in range(n)], int(nsel.value)
+
+
+def prepare_aggregate(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                      exprs: Sequence[CompiledExpression], aggs: Sequence[int]) -> None:
+    fns = (C.c_int32 * max(1, len(exprs)))(*[int(a) for a in aggs])
+    N.check(ctx.handle, ctx._lib.qe_filter_aggregate_prepare(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                             _expr_array(exprs), fns, len(exprs)))

@@ -157,6 +157,9 @@ def test_planning_context_generates_and_compiles_kernels_without_gpu(plan_ctx):
         src = E.generated_source(plan_ctx, batch, cf, cp)
         assert "qe_fused" in src and "__builtin_nontemporal_load" in src and "qe_lookback" in src
         E.prepare(plan_ctx, batch, cf, cp)                 # hiprtc cross-compiles for gfx950 with no device
+        if all(p.dataType.is_numeric for p in wl.projections):
+            E.prepare_aggregate(plan_ctx, batch, cf, cp, [N.AGG_SUM] * len(cp))
+            E.prepare_aggregate(plan_ctx, batch, None, cp[:1], [N.AGG_MIN])
     # but nothing can EXECUTE without a device: there is no CPU fallback
     with pytest.raises(N.QeError) as ei:
         E.filter_project(plan_ctx, batch, cf, cp)
