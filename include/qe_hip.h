@@ -236,6 +236,11 @@ int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_ex
 /* measured device read bandwidth of a plain streaming kernel over nbytes (GB/s): roofline calibration */
 int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, double *out_gbps);
 
+/* calibration: time (ms) of streaming nbytes with one 512-byte block WRITTEN per wave every `write_every`
+ * 8-KiB read iterations (0 = read only); what a trickle of writes costs a read stream on this device */
+int32_t qe_stream_read_write_time(qe_ctx *ctx, int64_t nbytes, int32_t write_every, int32_t reps, double *out_ms,
+                                  double *out_written_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,6 +449,39 @@ int32_t qe_expr_compile(qe_ctx *ctx, const uint8_t *program, size_t len, qe_expr
 int32_t qe_expr_result_type(const qe_expr *e) { return e ? e->e.nodes[e->e.root].type : -1; }
 void qe_expr_free(qe_ctx *, qe_expr *e) { delete e; }
 
+
+int32_t qe_stream_read_write_time(qe_ctx *ctx, int64_t nbytes, int32_t write_every, int32_t reps, double *out_ms,
+                                  double *out_written_bytes) {
+    if (!ctx || nbytes < 4096 || reps < 1 || !out_ms) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        // write_every packs: [write_every % 1000] + 1000 * window_period_us + 1e7 * window_len_us
+        const int we = write_every % 1000;
+        const int64_t dst_bytes = we > 0 ? nbytes / 16 / we + (1 << 22) : (1 << 22);
+        void *buf = ctx->pool.alloc((size_t)nbytes);
+        void *dst = ctx->pool.alloc((size_t)dst_bytes);
+        struct G { qe_ctx *c; void *a, *b; ~G() { c->pool.release(a); c->pool.release(b); } } g{ctx, buf, dst};
+        QE_HIP(hipMemsetAsync(buf, 0x5a, (size_t)nbytes, ctx->stream));
+        double best = 1e30;
+        for (int r = 0; r <= reps; r++) {
+            QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+            launch_stream_read_write(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8), dst, dst_bytes,
+                                     write_every % 1000, ((write_every / 1000) % 10000) * 100, (write_every / 10000000) * 100);
+            QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            if (r > 0) best = std::min(best, (double)ms);
+        }
+        *out_ms = best;
+        if (out_written_bytes) {
+            // iterations per wave = nvec / (8 * threads); one 512-byte block per write_every iterations
+            const double iters = (double)(nbytes / 16) / (8.0 * 256 * 8 * 256);
+            *out_written_bytes = we > 0 ? std::floor(iters / we) * 512.0 * (256 * 8 * 4) : 0.0;
+        }
+    });
+}
+
 }  // extern "C"
 
 // ---- plans --------------------------------------------------------------------------------------------
@@ -462,11 +495,14 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     if (mw >= 1 && mw <= 8) g.min_waves = mw;
     if (u >= 1 && u <= 16) g.unroll = u;
     const int spc = ctx->opts.tuning[4];
-    if (spc >= 16 && spc <= 4096) g.subs_per_chunk = (spc + 15) & ~15;
+    if (spc >= 1 && spc <= 4096) g.subs_per_chunk = spc;
     const int lbk = ctx->opts.tuning[6];
     if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
+    const int pm = ctx->opts.tuning[2] / 10;   // tuning[2] = 10 * (prio_mode + 1) + nt ; 0 = default
+    if (pm >= 1 && pm <= 3) g.prio_mode = pm - 1;
     const int st7 = ctx->opts.tuning[7];
     if (st7 == 2) g.stagger = 0;
+    if (st7 == 1 && g.subs_per_chunk % 16 == 0) g.stagger = 1;
     if (st7 >= 10) g.resolve_at = st7 - 10;   // 10 + n: resolve n sub-tiles into the next chunk
     return g;
 }
@@ -486,11 +522,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     }
     in.cmp_semantics = ctx->opts.cmp_semantics;
     in.geo = geometry_of(ctx);
-    in.nontemporal = ctx->opts.tuning[2] == 2 ? 0 : 1;
+    in.nontemporal = ctx->opts.tuning[2] % 10 == 2 ? 0 : 1;
     in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -683,7 +719,11 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         qe_ctx *c; std::vector<void *> &v;
         ~ScratchGuard() { for (void *q : v) c->pool.release(q); }
     } sg{ctx, scratch};
-    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 8);
+    // descriptors: [nchunks] level 0, then [nblocks] level 1, then [nblocks] block counters -- one allocation,
+    // zeroed by ONE memset on the stream before every launch
+    const int64_t nblocks = (nchunks + 63) / 64;
+    const size_t desc_words = (size_t)nchunks + 2 * (size_t)nblocks;
+    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc(desc_words * 8);
     scratch.push_back(desc);
     if (plan->cg.has_filter) {
         const size_t slots = (size_t)grid * waves * 2;   // two staging slots per resident wave (deferred resolve)
@@ -700,19 +740,38 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     }
     p.capacity = cap;
     p.desc = desc;
+    p.l1 = desc + nchunks;
+    p.blk = desc + nchunks + nblocks;
     p.ticket = ctx->d_ctrl;
     p.error = ctx->d_ctrl + 1;
     p.total = (unsigned long long *)(ctx->d_ctrl + 2);
     p.nchunks = nchunks;
     p.stagger_chunks = stagger_chunks;
     p.stagger_rows = stagger_rows;
+    p.stats = (unsigned long long *)(ctx->d_ctrl + 16);   // bytes 64..95 of the control block
+    if (ctx->opts.tuning[5] & 32) {
+        p.trace = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 32);
+        scratch.push_back(p.trace);
+        QE_HIP(hipMemsetAsync(p.trace, 0, (size_t)nchunks * 32, ctx->stream));
+    }
     // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
-    QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));
-    QE_HIP(hipMemsetAsync(desc, 0, (size_t)nchunks * 8, ctx->stream));
+    QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+    QE_HIP(hipMemsetAsync(desc, 0, desc_words * 8, ctx->stream));
     launch_fused(ctx, *plan, p, grid);
-    QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
     QE_HIP(hipStreamSynchronize(ctx->stream));
     collect_time(ctx);
+    if ((ctx->opts.tuning[5] & 32) && std::getenv("QE_TRACE_FILE")) {
+        std::vector<unsigned long long> tr((size_t)nchunks * 4);
+        QE_HIP(hipMemcpy(tr.data(), p.trace, tr.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = std::fopen(std::getenv("QE_TRACE_FILE"), "wb")) {
+            std::fwrite(tr.data(), 8, tr.size(), f);
+            std::fclose(f);
+        }
+    }
+    if (ctx->opts.tuning[5] & 16)
+        std::fprintf(stderr, "[qe stats] chunks %llu failed_tries %llu forced_waits %llu blocking_spins %llu\n", ctx->h_ctrl[11],
+                     ctx->h_ctrl[8], ctx->h_ctrl[10], ctx->h_ctrl[9]);
     const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
     if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
     const unsigned long long total = ctx->h_ctrl[1];

@@ -148,10 +148,13 @@ struct FusedGeometry {
     int threads = 256;
     int rows_per_lane = 2;
     int unroll = 8;          // load groups (of 128 rows) per sub-tile
-    int subs_per_chunk = 16; // sub-tiles per chunk (one ticket + one look-back per chunk); multiple of 16
+    int subs_per_chunk = 4;  // sub-tiles per chunk (one ticket + one look-back per chunk)
+    int ring_entries = 256;  // LDS entries per wave, buffer and output column: a chunk's kept rows stay in LDS
+                             // until it is resolved; only an overflow spills to the global staging slot
     int lookback_k = 4;      // descriptor windows (of 64) loaded per look-back round
-    int stagger = 1;         // grade the sizes of the first chunks
+    int stagger = 0;         // grade the sizes of the first chunks (needs subs_per_chunk % 16 == 0)
     int min_waves = 4;       // __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow
+    int prio_mode = 1;       // 0 off, 1 rotate s_setprio among the waves of a SIMD per sub-tile, 2 per chunk
     int resolve_at = 1;      // sub-tiles into the next chunk from which the previous chunk's resolve is tried
     int sub_rows() const { return 64 * rows_per_lane * unroll; }
     int chunk_rows() const { return sub_rows() * subs_per_chunk; }
@@ -221,7 +224,9 @@ struct FusedParams {
     unsigned char *stagevalid[kMaxOuts];
     long long nrows;
     long long capacity;
-    unsigned long long *desc;    // per-chunk look-back descriptors (zeroed per launch)
+    unsigned long long *desc;    // level-0 look-back descriptors, one per chunk (zeroed per launch)
+    unsigned long long *l1;      // level-1 descriptors, one per block of 64 chunks (zeroed per launch)
+    unsigned long long *blk;     // per-block packed {finished chunks, sum of counts} (zeroed per launch)
     unsigned int *ticket;        // chunk ticket counter (zeroed per launch)
     unsigned long long *total;   // out: number of selected rows
     unsigned int *error;         // out: nonzero when a bounded spin gave up
@@ -229,6 +234,8 @@ struct FusedParams {
     long long nchunks;
     long long stagger_chunks;
     long long stagger_rows;
+    unsigned long long *trace;
+    unsigned long long *stats;
 };
 
 }  // namespace qe

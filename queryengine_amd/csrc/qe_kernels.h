@@ -14,4 +14,8 @@ void launch_pack_bytes(hipStream_t s, const uint8_t *bytes, int64_t n, uint64_t 
 // plain streaming read of nbytes (16 B per lane), result folded into sink[0] so nothing is elided
 void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink);
 
+// read stream + a trickle of writes (one 512-byte block per wave every `write_every` read iterations of 8 KiB)
+void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, void *dst,
+                              int64_t dst_bytes, int write_every, int window_period, int window_len);
+
 }  // namespace qe

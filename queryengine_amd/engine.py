@@ -86,6 +86,12 @@ class Context:
         N.check(self.handle, self._lib.qe_stream_read_bandwidth(self.handle, nbytes, reps, C.byref(out)))
         return out.value
 
+    def stream_read_write_time(self, nbytes: int, write_every: int, reps: int = 5):
+        """(ms, bytes written) of a read stream with a trickle of writes: roofline calibration."""
+        ms, wb = C.c_double(), C.c_double()
+        N.check(self.handle, self._lib.qe_stream_read_write_time(self.handle, nbytes, write_every, reps, C.byref(ms), C.byref(wb)))
+        return ms.value, wb.value
+
     def dictionary(self, entries: Sequence[str]) -> "Dictionary":
         key = tuple(entries)
         d = self._dicts.get(key)

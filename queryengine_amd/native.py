@@ -94,6 +94,7 @@ SYMBOLS = [
     ("qe_result_free", None, [_P, _P]),
     ("qe_filter_project_source", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_char_p)]),
     ("qe_stream_read_bandwidth", C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
+    ("qe_stream_read_write_time", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""What does a trickle of writes cost a 24 GB read stream? (roofline calibration)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from queryengine_amd import engine as E
+ctx = E.Context(device=0)
+n = 24 << 30
+for we in (0, 16, 2):
+    ms, wb = ctx.stream_read_write_time(n, we, 5)
+    print(f"write_every {we:3d} (no gating): {ms:.3f} ms  read {n/1e9:.1f} GB  written {wb/1e9:.3f} GB  -> {(n+wb)/ms/1e6:.0f} GB/s total")
+# gate the writes into device-wide windows (period / length in 10 ns ticks of the shared 100 MHz clock)
+for period_us, len_us in ((50, 5), (100, 5), (100, 10), (200, 10), (200, 20), (400, 20), (1000, 50)):
+    for we in (2,):
+        code = we + 1000 * period_us + 10000000 * len_us
+        ms, wb = ctx.stream_read_write_time(n, code, 5)
+        print(f"write_every {we} window {len_us} us every {period_us} us: {ms:.3f} ms  written {wb/1e9:.3f} GB")
