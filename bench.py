@@ -150,6 +150,15 @@ def main():
             stream_gbps = ctx.stream_read_bandwidth(min(8 << 30, max(1 << 28, nrows * 8)), 5)
         except Exception:
             stream_gbps = None
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+        # WRITE_SIZE, separate passes; profiles/README.md) -- only valid for the workload it was collected on
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("workload") == wl.name and tj.get("rows") == nrows and args.exec_mode == "fused":
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+        except Exception:
+            pass
         out = {
             "metric": "rows/sec filter+project over int64/f64 batch (1B rows per GPU); achieved HBM GB/s in roofline",
             "value": world * nrows * args.steps / dt_max,
@@ -162,7 +171,7 @@ def main():
                        "selected_rows_total": total_out, "exec_mode": args.exec_mode,
                        "sharding": "contiguous row ranges by global row index, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "qe_fused", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_stream_read_gbps": stream_gbps},
         }

@@ -157,7 +157,8 @@ int32_t qe_batch_describe(qe_ctx *ctx, int64_t nrows, int32_t ncols, const qe_co
 /* synthetic columns generated on the device from the GLOBAL row index;
  * avoids a 24 GB H2D for the 1 B-row configurations and makes shards reproducible */
 enum { QE_GEN_I64_MOD = 0, QE_GEN_I32_MOD = 1, QE_GEN_F64_UNIT = 2, QE_GEN_F64_MOD = 3, QE_GEN_F64_STEP = 4,
-       QE_GEN_F64_PRICE = 5, QE_GEN_DICT_MOD = 6 };
+       QE_GEN_F64_PRICE = 5, QE_GEN_DICT_MOD = 6,
+       QE_GEN_I64_ROWID = 7 /* value = global row index: order-preservation checks */ };
 typedef struct {
     int32_t kind;
     int32_t col_id;       /* random stream id */

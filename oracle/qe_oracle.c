@@ -477,6 +477,7 @@ void qo_generate(const qo_gen_spec *s, uint64_t seed, int64_t row_begin, int64_t
         uint64_t x = qo_gen_raw(seed, s->col_id, i);
         switch (s->kind) {
         case QO_GEN_I64_MOD: ((int64_t *)data)[k] = (int64_t)(x % s->modulus) + s->offset; break;
+        case QO_GEN_I64_ROWID: ((int64_t *)data)[k] = (int64_t)i; break;
         case QO_GEN_I32_MOD: ((int32_t *)data)[k] = (int32_t)((int64_t)(x % s->modulus) + s->offset); break;
         case QO_GEN_F64_UNIT: ((double *)data)[k] = (double)(x >> 11) * 0x1.0p-53; break;
         case QO_GEN_F64_MOD: ((double *)data)[k] = (double)((int64_t)(x % s->modulus) + s->offset); break;

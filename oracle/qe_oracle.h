@@ -111,7 +111,7 @@ int64_t qo_filter_aggregate(const qo_node *nodes, int32_t filter_root, const int
 
 /* synthetic column generator; same formulas as the device generator */
 enum { QO_GEN_I64_MOD = 0, QO_GEN_I32_MOD = 1, QO_GEN_F64_UNIT = 2, QO_GEN_F64_MOD = 3, QO_GEN_F64_STEP = 4,
-       QO_GEN_F64_PRICE = 5 };
+       QO_GEN_F64_PRICE = 5, QO_GEN_I64_ROWID = 7 };
 typedef struct {
     int32_t kind;
     int32_t col_id;     /* stream id of this column */

@@ -368,7 +368,7 @@ int32_t qe_batch_generate(qe_ctx *ctx, uint64_t seed, int64_t row_begin, int64_t
             const qe_gen_spec &g = specs[j];
             Column c;
             switch (g.kind) {
-            case QE_GEN_I64_MOD: c.type = QE_INT64; break;
+            case QE_GEN_I64_MOD: case QE_GEN_I64_ROWID: c.type = QE_INT64; break;
             case QE_GEN_I32_MOD: c.type = QE_INT32; break;
             case QE_GEN_DICT_MOD:
                 c.type = QE_STRING;
@@ -380,7 +380,7 @@ int32_t qe_batch_generate(qe_ctx *ctx, uint64_t seed, int64_t row_begin, int64_t
             case QE_GEN_F64_UNIT: case QE_GEN_F64_MOD: case QE_GEN_F64_STEP: case QE_GEN_F64_PRICE: c.type = QE_DOUBLE; break;
             default: fail(QE_ERR_INVALID_ARG, "bad generator kind");
             }
-            if (g.kind != QE_GEN_F64_UNIT && g.kind != QE_GEN_F64_PRICE && g.modulus == 0)
+            if (g.kind != QE_GEN_F64_UNIT && g.kind != QE_GEN_F64_PRICE && g.kind != QE_GEN_I64_ROWID && g.modulus == 0)
                 fail(QE_ERR_INVALID_ARG, "generator modulus must be > 0");
             c.data = ctx->pool.alloc(std::max<size_t>(column_bytes(c.type, nrows), 16));
             if (g.null_pct > 0 && nrows > 0) c.validity = (uint64_t *)ctx->pool.alloc(bitmap_bytes(nrows));

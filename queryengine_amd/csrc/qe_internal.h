@@ -148,10 +148,10 @@ struct FusedGeometry {
     int threads = 256;
     int rows_per_lane = 2;
     int unroll = 8;          // load groups (of 128 rows) per sub-tile
-    int subs_per_chunk = 4;  // sub-tiles per chunk (one ticket + one look-back per chunk)
+    int subs_per_chunk = 16; // sub-tiles per chunk (one ticket + one look-back per chunk)
     int ring_entries = 256;  // LDS entries per wave, buffer and output column: a chunk's kept rows stay in LDS
                              // until it is resolved; only an overflow spills to the global staging slot
-    int lookback_k = 4;      // descriptor windows (of 64) loaded per look-back round
+    int lookback_k = 1;      // descriptor windows (of 64) loaded per look-back round
     int stagger = 0;         // grade the sizes of the first chunks (needs subs_per_chunk % 16 == 0)
     int min_waves = 4;       // __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow
     int prio_mode = 1;       // 0 off, 1 rotate s_setprio among the waves of a SIMD per sub-tile, 2 per chunk

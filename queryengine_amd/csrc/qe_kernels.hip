@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) generate_kernel(const GenArgs a) {
         if (in) {
             switch (a.kind) {
             case QE_GEN_I64_MOD: ((i64 *)a.data)[k] = (i64)(x % a.modulus) + a.offset; break;
+            case QE_GEN_I64_ROWID: ((i64 *)a.data)[k] = (i64)i; break;
             case QE_GEN_I32_MOD:
             case QE_GEN_DICT_MOD: ((int *)a.data)[k] = (int)((i64)(x % a.modulus) + a.offset); break;
             case QE_GEN_F64_UNIT: ((double *)a.data)[k] = (double)(x >> 11) * 0x1.0p-53; break;

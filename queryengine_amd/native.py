@@ -22,7 +22,7 @@ ERR_NAMES = {1: "INVALID_ARG", 2: "PROGRAM", 3: "HIP", 4: "OOM", 5: "UNSUPPORTED
 DEVICE_NONE = -1
 EXEC_FUSED, EXEC_PER_NODE = 0, 1
 CMP_TOTAL_ORDER, CMP_IEEE = 0, 1
-GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE, GEN_DICT_MOD = range(7)
+GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE, GEN_DICT_MOD, GEN_I64_ROWID = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_COUNT, AGG_AVG = range(5)
 
 

@@ -264,3 +264,42 @@ def test_large_batch_properties(gpu_ctx, oracle):
     c2 = r2.to_columns()
     assert np.array_equal(c1[0].data, c2[0].data) and np.array_equal(c1[1].data, c2[1].data)
     r1.free(); r2.free(); batch.free()
+
+
+def test_full_size_1b_rows_properties(gpu_ctx, oracle):
+    """BASELINE config 2 at its full size (1 B rows): properties that do not need the oracle to walk the
+    batch -- the projected global row ids are strictly increasing (order preserved, nothing duplicated),
+    every output row satisfies the predicate, count == the independent aggregate COUNT == popcount of the
+    predicate over two far-apart windows walked by the oracle, and a second run is identical."""
+    n = 1_000_000_000
+    specs = []
+    for kind, cid, mod in ((N.GEN_I64_MOD, 0, 1000), (N.GEN_I64_ROWID, 1, 0), (N.GEN_F64_UNIT, 2, 0)):
+        s = N.GenSpec(); s.kind = kind; s.col_id = cid; s.modulus = mod
+        specs.append(s)
+    batch = E.DeviceBatch.generate(gpu_ctx, specs, n)
+    A_, R_, C_ = col("a", 0, I64), col("rowid", 1, I64), col("c", 2, D)
+    flt = fn(Fn.AND, fn(Fn.CMP_LT, A_, num(100)), fn(Fn.CMP_LT, C_, num(0.5)))
+    cf = gpu_ctx.compile(flt)
+    projs = [gpu_ctx.compile(R_), gpu_ctx.compile(fn(Fn.ADD, A_, R_)), gpu_ctx.compile(fn(Fn.MUL, C_, num(2.0)))]
+    r1 = E.filter_project(gpu_ctx, batch, cf, projs)
+    rid, apr, c2 = (c.data for c in r1.to_columns())
+    assert abs(r1.count / n - 0.05) < 0.0005
+    assert np.all(np.diff(rid) > 0) and rid[0] >= 0 and rid[-1] < n          # stable, no duplicates
+    assert np.all(apr - rid < 100) and np.all(apr - rid >= 0) and np.all(c2 < 1.0)
+    vals, nsel = E.filter_aggregate(gpu_ctx, batch, cf, [gpu_ctx.compile(C_)], [N.AGG_COUNT])
+    assert nsel == r1.count == int(vals[0])
+    # two windows checked row by row against the oracle (which is far too slow for 1 B rows)
+    for begin in (0, 999_000_000 - 999_000_000 % 64):
+        m = 500_000
+        win = [batch.column_to_host(j, begin, m) for j in range(3)]
+        want = oracle.filter_project(win, flt, [R_, fn(Fn.ADD, A_, R_), fn(Fn.MUL, C_, num(2.0))], oracle.BYTECODE_COMPILER)
+        lo = np.searchsorted(rid, begin)
+        k = len(want[0])
+        assert np.array_equal(rid[lo:lo + k], want[0].data)
+        assert np.array_equal(apr[lo:lo + k], want[1].data)
+        assert np.array_equal(c2[lo:lo + k].view(np.uint64), want[2].data.view(np.uint64))
+        assert lo + k == len(rid) or rid[lo + k] >= begin + m
+    r2 = E.filter_project(gpu_ctx, batch, cf, projs)
+    assert r2.count == r1.count and np.array_equal(r2.column_to_host(0).data, rid)
+    r1.free(); r2.free(); batch.free()
+    gpu_ctx.trim()
