@@ -65,11 +65,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's BASELINE size, 1e9 for config2)")
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", default="", help="comma separated kernel tuning knobs (threads,unroll,nt,blocks_per_cu)")
     ap.add_argument("--exec-mode", default="fused", choices=["fused", "per_node"])
+    ap.add_argument("--selectivity", type=float, default=None, help="config2 only: target selectivity (changes the literals)")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the result to rank 0")
     args = ap.parse_args()
 
@@ -95,7 +96,14 @@ def main():
     from queryengine_amd import native as N
     from queryengine_amd import workloads as W
 
+    if args.rows is None:
+        args.rows = W.WORKLOADS[args.workload]().default_rows
     wl = W.WORKLOADS[args.workload](args.rows)
+    if args.selectivity is not None and args.workload == "config2":
+        # a < 1000 * s / c_limit with c < c_limit: sweep 1 %, 10 %, 50 %, 100 % as BASELINE.md section 3 asks
+        s_ = max(0.0, min(1.0, args.selectivity))
+        c_limit = 0.5 if s_ <= 0.5 else 1.0
+        wl = W.config2(args.rows, a_limit=round(1000 * s_ / c_limit), c_limit=c_limit)
     tuning = [int(x) for x in args.tuning.split(",") if x]
     ctx = E.Context(device=local_rank, profile=True, tuning=tuning,
                     exec_mode=N.EXEC_FUSED if args.exec_mode == "fused" else N.EXEC_PER_NODE)
@@ -178,7 +186,7 @@ def main():
         if gather_info is not None:
             out["gather"] = gather_info
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W.WORKLOADS[args.workload](args.rows))
+            out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     batch.free()
     ctx.close()
