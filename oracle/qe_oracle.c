@@ -53,6 +53,13 @@ static double java_max(double a, double b) {
     return a > b ? a : b;
 }
 
+static uint64_t mix64_fwd(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
 /* ---------- boxed values --------------------------------------------------- */
 
 static qo_value v_null(void) { qo_value v; memset(&v, 0, sizeof v); v.tag = QO_T_NULL; return v; }
@@ -454,6 +461,124 @@ int64_t qo_filter_aggregate(const qo_node *nodes, int32_t filter_root, const int
         out_values[k] = cnt[k] == 0 ? 0.0 : (agg_fns[k] == QO_AVG ? acc[k] / (double)cnt[k] : acc[k]);
     }
     return nsel;
+}
+
+/* ---------- group by ------------------------------------------------------------ */
+
+#include <stdlib.h>
+
+/* Any?.equals for group keys: Array.contentEquals (GroupByAggregationOperator.kt:9-11) */
+static int key_value_equals(const qo_value *a, const qo_value *b) {
+    if (a->tag != b->tag) return 0;
+    switch (a->tag) {
+    case QO_T_NULL: return 1;
+    case QO_T_F64: return qo_double_equals(a->u.d, b->u.d);
+    case QO_T_BOOL: return a->u.b == b->u.b;
+    case QO_T_STR: return strcmp(a->u.s, b->u.s) == 0;
+    case QO_T_I64: return a->u.l == b->u.l;
+    case QO_T_I32: return a->u.i == b->u.i;
+    default: return 0;
+    }
+}
+
+static uint64_t key_value_hash(const qo_value *v) {
+    switch (v->tag) {
+    case QO_T_F64: return mix64_fwd((uint64_t)double_to_long_bits(v->u.d) + 1);
+    case QO_T_BOOL: return mix64_fwd((uint64_t)v->u.b + 11);
+    case QO_T_I64: return mix64_fwd((uint64_t)v->u.l + 3);
+    case QO_T_I32: return mix64_fwd((uint64_t)(int64_t)v->u.i + 5);
+    case QO_T_STR: {
+        uint64_t h = 1469598103934665603ULL;
+        for (const unsigned char *c = (const unsigned char *)v->u.s; *c; c++) { h ^= *c; h *= 1099511628211ULL; }
+        return h;
+    }
+    default: return 0x9E3779B97F4A7C15ULL;
+    }
+}
+
+int64_t qo_filter_groupby(const qo_node *nodes, int32_t filter_root, const int32_t *key_roots, int32_t nkeys,
+                          const int32_t *expr_roots, const int32_t *agg_fns, int32_t nagg,
+                          const qo_column *cols, int32_t ncols, int64_t nrows, int32_t mode, int64_t max_groups,
+                          qo_out_column *out_keys, double *out_values, uint8_t *out_valid, int32_t *err) {
+    qo_value row[QO_MAX_COLS], key[QO_MAX_COLS];
+    *err = QO_OK;
+    if (ncols > QO_MAX_COLS || nagg > QO_MAX_COLS || nkeys > QO_MAX_COLS || max_groups < 0) { *err = QO_BAD_ARG; return -1; }
+    /* insertion-ordered map: groups[] in first-appearance order + open-addressing index */
+    int64_t cap = 16;
+    while (cap < 2 * max_groups + 2) cap <<= 1;
+    int64_t *index = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    qo_value *gkeys = (qo_value *)malloc((size_t)(max_groups + 1) * (size_t)(nkeys ? nkeys : 1) * sizeof(qo_value));
+    double *acc = (double *)malloc((size_t)(max_groups + 1) * (size_t)(nagg ? nagg : 1) * sizeof(double));
+    int64_t *cnt = (int64_t *)malloc((size_t)(max_groups + 1) * (size_t)(nagg ? nagg : 1) * sizeof(int64_t));
+    int64_t ngroups = 0;
+    if (!index || !gkeys || !acc || !cnt) { *err = QO_BAD_ARG; ngroups = -1; goto done; }
+    for (int64_t i = 0; i < cap; i++) index[i] = -1;
+    for (int64_t i = 0; i < nrows; i++) {
+        scan_row(cols, ncols, i, row);
+        if (filter_root >= 0) {
+            qo_value res;
+            int32_t st = qo_eval(nodes, filter_root, row, mode, &res);
+            if (st) { *err = st; ngroups = -1; goto done; }
+            if (res.tag != QO_T_BOOL || !res.u.b) continue;
+        }
+        uint64_t h = 0x243F6A8885A308D3ULL;
+        for (int32_t k = 0; k < nkeys; k++) {
+            int32_t st = qo_eval(nodes, key_roots[k], row, mode, &key[k]);
+            if (st) { *err = st; ngroups = -1; goto done; }
+            h = mix64_fwd(h ^ key_value_hash(&key[k]));
+        }
+        int64_t slot = (int64_t)(h & (uint64_t)(cap - 1)), g = -1;
+        for (;;) {   /* map.computeIfAbsent(key) (:35-37) */
+            int64_t cand = index[slot];
+            if (cand < 0) break;
+            int eq = 1;
+            for (int32_t k = 0; k < nkeys && eq; k++) eq = key_value_equals(&gkeys[cand * nkeys + k], &key[k]);
+            if (eq) { g = cand; break; }
+            slot = (slot + 1) & (cap - 1);
+        }
+        if (g < 0) {
+            if (ngroups >= max_groups) { *err = QO_BAD_ARG; ngroups = -1; goto done; }
+            g = ngroups++;
+            index[slot] = g;
+            for (int32_t k = 0; k < nkeys; k++) gkeys[g * nkeys + k] = key[k];
+            for (int32_t a = 0; a < nagg; a++) {
+                cnt[g * nagg + a] = 0;
+                acc[g * nagg + a] = agg_fns[a] == QO_MIN ? INFINITY : (agg_fns[a] == QO_MAX ? -INFINITY : 0.0);
+            }
+        }
+        for (int32_t a = 0; a < nagg; a++) {   /* :39-44 */
+            qo_value v;
+            int32_t st = qo_eval(nodes, expr_roots[a], row, mode, &v);
+            if (st) { *err = st; ngroups = -1; goto done; }
+            if (v.tag == QO_T_NULL) continue;
+            cnt[g * nagg + a]++;
+            if (agg_fns[a] == QO_COUNT) continue;
+            if (!is_numeric(&v)) { *err = QO_THROWN; ngroups = -1; goto done; }
+            double d = as_f64(&v);
+            switch (agg_fns[a]) {
+            case QO_SUM: case QO_AVG: acc[g * nagg + a] += d; break;
+            case QO_MIN: acc[g * nagg + a] = java_min(acc[g * nagg + a], d); break;
+            case QO_MAX: acc[g * nagg + a] = java_max(acc[g * nagg + a], d); break;
+            default: *err = QO_BAD_ARG; ngroups = -1; goto done;
+            }
+        }
+    }
+    for (int64_t g = 0; g < ngroups; g++) {
+        for (int32_t k = 0; k < nkeys; k++) {
+            int32_t st = store_out(&out_keys[k], g, &gkeys[g * nkeys + k]);
+            if (st) { *err = st; ngroups = -1; goto done; }
+        }
+        for (int32_t a = 0; a < nagg; a++) {
+            int64_t c = cnt[g * nagg + a];
+            double x = acc[g * nagg + a];
+            if (agg_fns[a] == QO_COUNT) { out_values[g * nagg + a] = (double)c; out_valid[g * nagg + a] = 1; continue; }
+            out_valid[g * nagg + a] = c != 0;
+            out_values[g * nagg + a] = c == 0 ? 0.0 : (agg_fns[a] == QO_AVG ? x / (double)c : x);
+        }
+    }
+done:
+    free(index); free(gkeys); free(acc); free(cnt);
+    return ngroups;
 }
 
 /* ---------- synthetic generator ----------------------- */

@@ -109,6 +109,17 @@ int64_t qo_filter_aggregate(const qo_node *nodes, int32_t filter_root, const int
                             const qo_column *cols, int32_t ncols, int64_t nrows, int32_t mode,
                             double *out_values, uint8_t *out_valid, int32_t *err);
 
+/* GroupByAggregation(Projection(Filter(Scan))) (operator/GroupByAggregationOperator.kt:7-76): the first nkeys
+ * expressions are the group key (boxed values compared with equals(): null == null, Double by bits with NaNs
+ * collapsed), the following nagg expressions feed one accumulator each (Accumulators.kt).  Groups come out in
+ * INSERTION order (LinkedHashMap, :22), which T/evaluator/QueryTest.kt:25-30 pins.
+ * out_keys[k] has capacity max_groups rows; out_values / out_valid are [group][agg] row-major.
+ * Returns the number of groups or -1 (*err set; QO_BAD_ARG also when max_groups is exceeded). */
+int64_t qo_filter_groupby(const qo_node *nodes, int32_t filter_root, const int32_t *key_roots, int32_t nkeys,
+                          const int32_t *expr_roots, const int32_t *agg_fns, int32_t nagg,
+                          const qo_column *cols, int32_t ncols, int64_t nrows, int32_t mode, int64_t max_groups,
+                          qo_out_column *out_keys, double *out_values, uint8_t *out_valid, int32_t *err);
+
 /* synthetic column generator; same formulas as the device generator */
 enum { QO_GEN_I64_MOD = 0, QO_GEN_I32_MOD = 1, QO_GEN_F64_UNIT = 2, QO_GEN_F64_MOD = 3, QO_GEN_F64_STEP = 4,
        QO_GEN_F64_PRICE = 5, QO_GEN_I64_ROWID = 7 };

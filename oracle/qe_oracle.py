@@ -83,6 +83,11 @@ def lib() -> C.CDLL:
         L.qo_filter_aggregate.argtypes = [C.POINTER(_Node), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                           C.c_int32, C.POINTER(_Column), C.c_int32, C.c_int64, C.c_int32,
                                           C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+        L.qo_filter_groupby.restype = C.c_int64
+        L.qo_filter_groupby.argtypes = [C.POINTER(_Node), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.c_int32, C.POINTER(_Column), C.c_int32, C.c_int64, C.c_int32,
+                                        C.c_int64, C.POINTER(_OutColumn), C.POINTER(C.c_double), C.POINTER(C.c_uint8),
+                                        C.POINTER(C.c_int32)]
         L.qo_generate.restype = None
         L.qo_generate.argtypes = [C.POINTER(GenSpec), C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         L.qo_gen_raw.restype = C.c_uint64
@@ -277,6 +282,56 @@ def filter_aggregate(cols: Sequence[Column], filter_expr: Optional[A.Expression]
             raise ReferenceWouldThrow()
         raise ValueError(f"oracle status {err.value}")
     return [float(vals[i]) if valid[i] else None for i in range(len(exprs))], int(n)
+
+
+def filter_groupby(cols: Sequence[Column], filter_expr: Optional[A.Expression], keys: Sequence[A.Expression],
+                   exprs: Sequence[A.Expression], aggs: Sequence[int], mode: int = INTERPRETER, max_groups: int = 1 << 20):
+    """GroupByAggregation(Projection(Filter(Scan))): rows [key values..., aggregate values...] in insertion order."""
+    nrows = len(cols[0]) if cols else 0
+    tb = _TreeBuilder()
+    froot = filter_expr.accept(tb) if filter_expr is not None else -1
+    kroots = [e.accept(tb) for e in keys]
+    roots = [e.accept(tb) for e in exprs]
+    keep: list = []
+    carr = _columns(cols, keep)
+    max_groups = min(max_groups, max(1, nrows))
+    kouts = (_OutColumn * max(1, len(keys)))()
+    kbufs = []
+    for k, e in enumerate(keys):
+        t = e.dataType
+        data = np.zeros(max_groups, dtype=_OUT_NP[t]); valid = np.zeros(max_groups, dtype=np.uint8)
+        kbufs.append((data, valid))
+        kouts[k].dtype = int(t); kouts[k].data = data.ctypes.data; kouts[k].valid = valid.ctypes.data
+    vals = np.zeros(max_groups * max(1, len(exprs)), dtype=np.float64)
+    vvalid = np.zeros(max_groups * max(1, len(exprs)), dtype=np.uint8)
+    err = C.c_int32(0)
+    n = lib().qo_filter_groupby(tb.array(), froot, (C.c_int32 * max(1, len(kroots)))(*kroots), len(kroots),
+                                (C.c_int32 * max(1, len(roots)))(*roots), (C.c_int32 * max(1, len(aggs)))(*[int(a) for a in aggs]),
+                                len(exprs), carr, len(cols), nrows, mode, max_groups, kouts,
+                                vals.ctypes.data_as(C.POINTER(C.c_double)), vvalid.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(err))
+    if n < 0:
+        if err.value == THROWN:
+            raise ReferenceWouldThrow()
+        raise ValueError(f"oracle status {err.value}")
+    rows = []
+    for g in range(n):
+        row = []
+        for (data, valid), e in zip(kbufs, keys):
+            if not valid[g]:
+                row.append(None)
+            elif e.dataType == DataType.STRING:
+                row.append(C.cast(int(data[g]), C.c_char_p).value.decode("utf-8"))
+            elif e.dataType == DataType.BOOLEAN:
+                row.append(bool(data[g]))
+            elif e.dataType == DataType.DOUBLE:
+                row.append(float(data[g]))
+            else:
+                row.append(int(data[g]))
+        for a in range(len(exprs)):
+            i = g * len(exprs) + a
+            row.append(float(vals[i]) if vvalid[i] else None)
+        rows.append(row)
+    return rows
 
 
 def generate(spec: GenSpec, seed: int, row_begin: int, nrows: int, np_dtype) -> Tuple[np.ndarray, Optional[np.ndarray]]:

@@ -500,7 +500,9 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
     const int pm = ctx->opts.tuning[2] / 10;   // tuning[2] = 10 * (prio_mode + 1) + nt ; 0 = default
     if (pm >= 1 && pm <= 3) g.prio_mode = pm - 1;
-    const int st7 = ctx->opts.tuning[7];
+    const int nb = ctx->opts.tuning[7] / 100;   // tuning[7] = 100 * nbuf + (stagger / resolve_at code)
+    if (nb >= 2 && nb <= 8) g.nbuf = nb;
+    const int st7 = ctx->opts.tuning[7] % 100;
     if (st7 == 2) g.stagger = 0;
     if (st7 == 1 && g.subs_per_chunk % 16 == 0) g.stagger = 1;
     if (st7 >= 10) g.resolve_at = st7 - 10;   // 10 + n: resolve n sub-tiles into the next chunk
@@ -526,7 +528,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -544,6 +546,25 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
     auto plan = std::make_shared<Plan>();
     plan->cg = generate_fused_source(in);
+    if (!agg_fns && in.filter) {
+        // LDS budget of the per-wave FIFO of chunk buffers: waves * nbuf * ring * (bytes per output row).
+        // Narrow rows get 3 buffers; wide rows 2 buffers and, if need be, fewer waves per workgroup so that a
+        // workgroup stays within the 160 KiB of a CU (and several workgroups still fit).
+        size_t rowbytes = 0;
+        for (const OutSpec &o : plan->cg.outs)
+            rowbytes += (o.type == QE_BOOLEAN ? 1 : (o.type == QE_DOUBLE || o.type == QE_INT64) ? 8 : 4) + (o.nullable ? 1 : 0);
+        rowbytes = std::max<size_t>(rowbytes, 1);
+        if (ctx->opts.tuning[7] / 100 == 0) in.geo.nbuf = rowbytes <= 16 ? 3 : 2;
+        if (ctx->opts.tuning[0] == 0) {
+            const size_t limit = 96 * 1024;
+            while (in.geo.threads > 64 && (size_t)(in.geo.threads / 64) * in.geo.nbuf * in.geo.ring_entries * rowbytes > limit)
+                in.geo.threads /= 2;
+        }
+        if ((size_t)(in.geo.threads / 64) * in.geo.nbuf * in.geo.ring_entries * rowbytes > 156 * 1024)
+            fail(QE_ERR_UNSUPPORTED, "projection list too wide for the fused kernel's LDS buffers (" + std::to_string(rowbytes) +
+                                         " bytes per output row); use QE_EXEC_PER_NODE");
+        plan->cg = generate_fused_source(in);
+    }
     if (ctx->opts.tuning[3] / 100 == 0) {
         // Register budget.  Per lane a sub-tile holds 2*U rows of every input column, later of every output
         // column, plus one VGPR per boolean per row: shrink the sub-tile of very wide plans first.  Then ask
@@ -726,7 +747,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     unsigned long long *desc = (unsigned long long *)ctx->pool.alloc(desc_words * 8);
     scratch.push_back(desc);
     if (plan->cg.has_filter) {
-        const size_t slots = (size_t)grid * waves * 2;   // two staging slots per resident wave (deferred resolve)
+        const size_t slots = (size_t)grid * waves * plan->geo.nbuf;   // one staging (overflow) slot per LDS buffer
         for (size_t i = 0; i < res->cols.size(); i++) {
             const OutColumn &oc = res->cols[i];
             const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);

@@ -27,14 +27,20 @@ static uint64_t fnv1a(const std::string &s) {
 }
 
 static const char *kArch = "gfx950";
+// part of the cache key: bump when the compile options below change
+static const char *kOptionsTag = "O3-nocontract-noatomicopt-v2";
 
 std::vector<char> Jit::compile(const std::string &source) {
     hiprtcProgram prog;
     hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "qe_fused.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) fail(QE_ERR_HIP, std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r));
     // -ffp-contract=off: the JVM's DMUL;DADD are separately rounded
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+    // -amdgpu-atomic-optimizer-strategy=None: every atomic of the generated kernels is issued by ONE lane and
+    // its result is consumed much later; the optimizer's wave-reduction form reads the result right away
+    // (s_waitcnt vmcnt(0) + v_readfirstlane), which exposed the full round trip of every ticket
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17",
+                          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"};
+    r = hiprtcCompileProgram(prog, 6, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -70,7 +76,7 @@ int Jit::scratch_bytes(const std::vector<char> &code) {
 
 Kernel Jit::get(const std::string &source, const char *entry, bool load) {
     char key[64];
-    std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source), source.size(), kArch);
+    std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source + kOptionsTag), source.size(), kArch);
     auto it = loaded_.find(key);
     if (it != loaded_.end()) {
         mem_hits++;
