@@ -208,6 +208,20 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
                             const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg,
                             double *out_values, uint8_t *out_valid, int64_t *out_selected_rows);
 
+/* GroupByAggregation(Projection(Filter(Scan))): GroupByAggregationOperator.open
+ * (operator/GroupByAggregationOperator.kt:21-49).  The result has nkeys key columns followed by nagg DOUBLE
+ * aggregate columns (NULL for an empty MIN/MAX/SUM/AVG, COUNT as a double), one row per group, in INSERTION
+ * order of the groups (LinkedHashMap, :22; pinned by T/evaluator/QueryTest.kt:25-30); NULL is a key value.
+ * Keys must be STRING (dictionary) or BOOLEAN expressions with at most 2^20 combinations.  SUM/AVG use native
+ * f64 atomics: exact when every partial sum is representable, otherwise order dependent in the last bits. */
+int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                          const qe_expr *const *keys, int32_t nkeys,
+                          const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg, qe_result **out);
+
+int32_t qe_filter_groupby_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                  const qe_expr *const *keys, int32_t nkeys,
+                                  const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg);
+
 /* plan-time preparation of the aggregate plan (JIT compile + cache), no execution */
 int32_t qe_filter_aggregate_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                     const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg);

@@ -510,7 +510,8 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
 }
 
 std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
-                               const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load) {
+                               const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load,
+                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0) {
     if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
     CodegenInput in;
     in.filter = filter ? &filter->e : nullptr;
@@ -521,6 +522,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
             if (agg_fns[i] < QE_AGG_MIN || agg_fns[i] > QE_AGG_AVG) fail(QE_ERR_UNSUPPORTED, "unsupported aggregation function");
             in.agg_fns.push_back(agg_fns[i]);
         }
+    }
+    for (int32_t i = 0; i < nkeys; i++) {
+        if (!keys || !keys[i]) fail(QE_ERR_INVALID_ARG, "null group key");
+        in.group_keys.push_back(&keys[i]->e);
     }
     in.cmp_semantics = ctx->opts.cmp_semantics;
     in.geo = geometry_of(ctx);
@@ -539,6 +544,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     };
     add_prog(in.filter);
     for (const Expr *e : in.projections) add_prog(e);
+    for (const Expr *e : in.group_keys) {
+        key << "|k";
+        add_prog(e);
+    }
     if (agg_fns)
         for (int a : in.agg_fns) key << "|a" << a;
     const std::string k = key.str();
@@ -932,6 +941,144 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
         if (ntiles > 0)
             for (int b = 0; b < grid; b++) nsel += (int64_t)partial[(size_t)b * stride + 2 * nagg];
         if (out_selected_rows) *out_selected_rows = nsel;
+    });
+}
+
+int32_t qe_filter_groupby_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *keys,
+                                  int32_t nkeys, const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg) {
+    if (!ctx || !batch || nkeys <= 0 || !keys || nagg <= 0 || !exprs || !agg_fns) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        if (ctx->device >= 0) need_device(ctx);
+        (void)get_plan(ctx, batch, filter, exprs, nagg, agg_fns, ctx->device >= 0, keys, nkeys);
+    });
+}
+
+int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *keys, int32_t nkeys,
+                          const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg, qe_result **out) {
+    if (!ctx || !batch || !out || nkeys <= 0 || !keys || nagg <= 0 || !exprs || !agg_fns) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
+        auto plan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true, keys, nkeys);
+        const CodegenOutput &cg = plan->cg;
+        const int64_t G = cg.ngroups;
+        const int W = cg.table_words;
+        // global accumulator table, initialised from the host (smallest row = ~0, MIN/MAX keys at their identity)
+        std::vector<unsigned long long> tab((size_t)G * W);
+        for (int64_t g = 0; g < G; g++) {
+            unsigned long long *e = &tab[(size_t)g * W];
+            e[0] = ~0ull;
+            for (int i = 0; i < nagg; i++) {
+                e[1 + 2 * i] = 0;
+                e[2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
+            }
+        }
+        unsigned long long *d_tab = (unsigned long long *)ctx->pool.alloc(tab.size() * 8);
+        struct G1 { qe_ctx *c; void *p; ~G1() { c->pool.release(p); } } g1{ctx, d_tab};
+        QE_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        const int64_t n = batch->nrows;
+        if (n > 0) {
+            const int64_t sub_rows = plan->geo.sub_rows();
+            const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
+            const int waves = plan->geo.threads / 64;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 4));
+            FusedParams p;
+            fill_inputs(p, batch, *plan);
+            p.agg_partial = (double *)d_tab;
+            launch_fused(ctx, *plan, p, grid);
+        }
+        QE_HIP(hipMemcpyAsync(tab.data(), d_tab, tab.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        if (n > 0) collect_time(ctx);
+        // groups in insertion order = ascending first row (LinkedHashMap order, GroupByAggregationOperator.kt:22)
+        std::vector<std::pair<unsigned long long, int64_t>> order;
+        for (int64_t g = 0; g < G; g++)
+            if (tab[(size_t)g * W] != ~0ull) order.emplace_back(tab[(size_t)g * W], g);
+        std::sort(order.begin(), order.end());
+        const int64_t m = (int64_t)order.size();
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
+        res->count = m;
+        res->capacity = m;
+        const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
+        auto upload = [&](const void *src, size_t bytes) -> void * {
+            void *d = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+            if (bytes) QE_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+            return d;
+        };
+        std::vector<std::vector<unsigned long long>> keep_words;   // host staging must outlive the async copies
+        std::vector<std::vector<int32_t>> keep_codes;
+        std::vector<std::vector<double>> keep_vals;
+        int64_t stride = 1;
+        for (size_t k = 0; k < cg.keys.size(); k++) {
+            const int domain = cg.key_domain[k];
+            OutColumn oc;
+            oc.type = cg.keys[k].type;
+            oc.dict = cg.keys[k].dict;
+            oc.dict_handle.d = oc.dict;
+            std::vector<unsigned long long> valid(words, 0), bits(words, 0);
+            std::vector<int32_t> codes((size_t)std::max<int64_t>(m, 1), 0);
+            bool any_null = false;
+            for (int64_t j = 0; j < m; j++) {
+                const int code = (int)((order[j].second / stride) % (domain + 1));
+                if (code == domain) { any_null = true; continue; }
+                valid[j >> 6] |= 1ull << (j & 63);
+                codes[j] = code;
+                if (code) bits[j >> 6] |= 1ull << (j & 63);
+            }
+            oc.nullable = any_null;
+            if (oc.type == QE_BOOLEAN) {
+                keep_words.push_back(bits);
+                oc.data = upload(keep_words.back().data(), words * 8);
+            } else {
+                keep_codes.push_back(codes);
+                oc.data = upload(keep_codes.back().data(), (size_t)m * 4);
+            }
+            if (any_null) {
+                keep_words.push_back(valid);
+                oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
+            }
+            res->cols.push_back(oc);
+            stride *= (domain + 1);
+        }
+        for (int i = 0; i < nagg; i++) {
+            OutColumn oc;
+            oc.type = QE_DOUBLE;
+            std::vector<double> vals((size_t)std::max<int64_t>(m, 1), 0.0);
+            std::vector<unsigned long long> valid(words, 0);
+            bool any_null = false;
+            for (int64_t j = 0; j < m; j++) {
+                const unsigned long long *e = &tab[(size_t)order[j].second * W];
+                const unsigned long long cnt = e[1 + 2 * i];
+                const unsigned long long raw = e[2 + 2 * i];
+                double v = 0.0;
+                bool ok = true;
+                switch (agg_fns[i]) {
+                case QE_AGG_COUNT: v = (double)cnt; break;                       // Accumulators.kt:26-36
+                case QE_AGG_SUM: std::memcpy(&v, &raw, 8); ok = cnt != 0; break;  // :47-53 empty => null
+                case QE_AGG_AVG: std::memcpy(&v, &raw, 8); ok = cnt != 0; if (ok) v /= (double)cnt; break;
+                default: {                                                        // MIN / MAX: undo the ordered key
+                    long long key = (long long)raw;
+                    long long b = key ^ ((key >> 63) & 0x7fffffffffffffffll);
+                    std::memcpy(&v, &b, 8);
+                    ok = cnt != 0;
+                }
+                }
+                if (ok) valid[j >> 6] |= 1ull << (j & 63);
+                else { any_null = true; v = 0.0; }
+                vals[j] = v;
+            }
+            oc.nullable = any_null;
+            keep_vals.push_back(vals);
+            oc.data = upload(keep_vals.back().data(), (size_t)m * 8);
+            if (any_null) {
+                keep_words.push_back(valid);
+                oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
+            }
+            res->cols.push_back(oc);
+        }
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        *out = res.release();
     });
 }
 

@@ -169,6 +169,7 @@ struct CodegenInput {
     const Expr *filter = nullptr;
     std::vector<const Expr *> projections;
     std::vector<int> agg_fns;  // non-empty: aggregate mode (one per projection)
+    std::vector<const Expr *> group_keys;  // aggregate mode only: non-empty => GROUP BY these (STRING / BOOLEAN) expressions
     std::vector<BoundColumn> schema;
     int cmp_semantics = QE_CMP_TOTAL_ORDER;
     FusedGeometry geo;
@@ -181,6 +182,13 @@ struct CodegenOutput {
     std::vector<OutSpec> outs;
     std::vector<int> used_cols;  // batch column index per kernel column slot
     bool has_filter = false;
+    // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
+    // accumulator table geometry: ngroups rows of table_words u64 words {first row, (count, acc) per aggregate}
+    std::vector<OutSpec> keys;
+    std::vector<int> key_domain;
+    long long ngroups = 0;
+    int table_words = 0;
+    bool table_in_lds = false;
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);

@@ -335,3 +335,20 @@ def prepare_aggregate(ctx: Context, batch: DeviceBatch, filter: Optional[Compile
     fns = (C.c_int32 * max(1, len(exprs)))(*[int(a) for a in aggs])
     N.check(ctx.handle, ctx._lib.qe_filter_aggregate_prepare(ctx.handle, batch.handle, filter.handle if filter else None,
                                                              _expr_array(exprs), fns, len(exprs)))
+
+
+def filter_groupby(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression], keys: Sequence[CompiledExpression],
+                   exprs: Sequence[CompiledExpression], aggs: Sequence[int]) -> Result:
+    """qe_filter_groupby: key columns + DOUBLE aggregate columns, one row per group in insertion order."""
+    h = C.c_void_p()
+    fns = (C.c_int32 * max(1, len(exprs)))(*[int(a) for a in aggs])
+    N.check(ctx.handle, ctx._lib.qe_filter_groupby(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                   _expr_array(keys), len(keys), _expr_array(exprs), fns, len(exprs), C.byref(h)))
+    return Result(ctx, h)
+
+
+def prepare_groupby(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression], keys: Sequence[CompiledExpression],
+                    exprs: Sequence[CompiledExpression], aggs: Sequence[int]) -> None:
+    fns = (C.c_int32 * max(1, len(exprs)))(*[int(a) for a in aggs])
+    N.check(ctx.handle, ctx._lib.qe_filter_groupby_prepare(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                           _expr_array(keys), len(keys), _expr_array(exprs), fns, len(exprs)))

@@ -86,6 +86,8 @@ SYMBOLS = [
     ("qe_filter_project_prepare", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32]),
     ("qe_filter_aggregate", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32,
                                         C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]),
+    ("qe_filter_groupby", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_P)]),
+    ("qe_filter_groupby_prepare", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32]),
     ("qe_filter_aggregate_prepare", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32]),
     ("qe_result_count", C.c_int64, [_P]),
     ("qe_result_ncols", C.c_int32, [_P]),

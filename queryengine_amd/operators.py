@@ -182,3 +182,105 @@ class GpuGlobalAggregationOperator(Operator):
     def close(self) -> None:
         self._row = None
         self.source.close()
+
+
+class GpuGroupByAggregationOperator(Operator):
+    """GroupByAggregation(Projection(Filter(Scan))) on the GPU.
+
+    Replaces GroupByAggregationOperator (operator/GroupByAggregationOperator.kt:7-76) over the inner projection:
+    one row [keys..., finished accumulators...] per group, in insertion order of the groups; null is a key value."""
+
+    def __init__(self, ctx: E.Context, source: ColumnarScanOperator, filter: Optional[Expression],
+                 keyExpressions: Sequence[Expression], expressions: Sequence[Expression],
+                 aggregateFunctions: Sequence[AggregationFunction]):
+        self.ctx = ctx
+        self.source = source
+        self._filter = ctx.compile(filter) if filter is not None else None
+        self._keys = [ctx.compile(e) for e in keyExpressions]
+        self._exprs = [ctx.compile(e) for e in expressions]
+        self._aggs = [int(a) for a in aggregateFunctions]
+        self._rows: Optional[List[List[Any]]] = None
+        self._idx = 0
+
+    def open(self) -> None:
+        self.source.open()
+        batch = self.source.device_batch(self.ctx)
+        res = E.filter_groupby(self.ctx, batch, self._filter, self._keys, self._exprs, self._aggs)
+        cols = res.to_columns()
+        res.free()
+        nk = len(self._keys)
+        rows = []
+        for i in range(len(cols[0]) if cols else 0):
+            row = [c.value(i) for c in cols]
+            for a, fn in enumerate(self._aggs):          # CountAccumulator.finish returns an Int (Accumulators.kt:26-36)
+                if fn == int(AggregationFunction.COUNT) and row[nk + a] is not None:
+                    row[nk + a] = int(row[nk + a])
+            rows.append(row)
+        self._rows = rows
+        self._idx = 0
+
+    def next(self) -> Optional[List[Any]]:
+        if self._rows is None:
+            raise RuntimeError("Operator not opened")      # GroupByAggregationOperator.kt:57
+        if self._idx >= len(self._rows):
+            return None
+        self._idx += 1
+        return self._rows[self._idx - 1]
+
+    def close(self) -> None:
+        self._rows = None
+        self.source.close()
+
+
+class GpuFinishProjectionOperator(Operator):
+    """The projection the reference puts on top of an aggregation (``groupByFinish``, RewriteAggregates.kt:29-47):
+    re-orders / combines the few aggregated rows.  The rows of the blocking source are pinned as one small batch and
+    the expressions run on the GPU like any other projection (no CPU evaluation)."""
+
+    def __init__(self, ctx: E.Context, source: Operator, sourceTypes: Sequence, expressions: Sequence[Expression]):
+        self.ctx = ctx
+        self.source = source
+        self.sourceTypes = list(sourceTypes)
+        self.expressions = list(expressions)
+        self._compiled = [ctx.compile(e) for e in expressions]
+        self._rows: Optional[List[List[Any]]] = None
+        self._idx = 0
+
+    def open(self) -> None:
+        from .ast import ColumnExpression
+        rows = map(self.source, lambda r: list(r))
+        if not rows:
+            self._rows = []
+            self._idx = 0
+            return
+        cols = []
+        for j, t in enumerate(self.sourceTypes):
+            vals = [r[j] for r in rows]
+            if t.name == "DOUBLE":
+                vals = [float(v) if v is not None else None for v in vals]   # COUNT arrives as an Int
+            cols.append(Column.from_values(t, vals))
+        batch = E.DeviceBatch.from_columns(self.ctx, cols)
+        res = E.filter_project(self.ctx, batch, None, self._compiled)
+        out = res.to_columns()
+        res.free()
+        batch.free()
+        result = []
+        for i in range(len(rows)):
+            row = [c.value(i) for c in out]
+            for k, e in enumerate(self.expressions):   # a bare reference to a COUNT column keeps the Int
+                if isinstance(e, ColumnExpression) and isinstance(rows[i][e.index], int) and not isinstance(rows[i][e.index], bool):
+                    row[k] = rows[i][e.index]
+            result.append(row)
+        self._rows = result
+        self._idx = 0
+
+    def next(self) -> Optional[List[Any]]:
+        if self._rows is None:
+            raise RuntimeError("Operator not initialized")
+        if self._idx >= len(self._rows):
+            return None
+        self._idx += 1
+        return self._rows[self._idx - 1]
+
+    def close(self) -> None:
+        self._rows = None

@@ -17,9 +17,10 @@ from typing import Any, List, Optional, Sequence
 from . import engine as E
 from . import native as N
 from .ast import (AggregationFunction, AggregationFunctionExpression, ColumnExpression, DefaultExpressionVisitor,
-                  Expression, IdentifierExpression)
+                  Expression, FunctionExpression, IdentifierExpression)
 from .datatypes import Field, Schema
-from .operators import (ColumnarScanOperator, GpuFilterProjectOperator, GpuGlobalAggregationOperator, Operator)
+from .operators import (ColumnarScanOperator, GpuFilterProjectOperator, GpuFinishProjectionOperator,
+                        GpuGlobalAggregationOperator, GpuGroupByAggregationOperator, Operator)
 from .operators import map as op_map
 from .sql import Query, parseQuery
 from .table import Table, TableRegistry
@@ -82,6 +83,62 @@ class _ResolveSchema(DefaultExpressionVisitor):
         return ColumnExpression(field.name, len(self.fields) - 1, field.type)
 
 
+class InvalidAggregatesException(RuntimeError):
+    """evaluator/RewriteAggregates.kt:7"""
+
+
+def _count_aggregates(expr: Expression) -> int:
+    """RewriteAggregates.kt:57-82 (CountAggregates)"""
+    if isinstance(expr, AggregationFunctionExpression):
+        if any(_count_aggregates(o) > 0 for o in expr.operands):
+            raise InvalidAggregatesException("Nested aggregates are not allowed")
+        return 1
+    if isinstance(expr, FunctionExpression):
+        return sum(_count_aggregates(o) for o in expr.operands)
+    return 0
+
+
+class _RewriteAggregates(DefaultExpressionVisitor):
+    """RewriteAggregates.kt:84-97: every aggregate call becomes a column of the aggregation's output."""
+
+    def __init__(self, groupExpressionCount: int):
+        self.groupExpressionCount = groupExpressionCount
+        self.aggregateInputs: List[Expression] = []
+        self.aggregateFunctions: List[AggregationFunction] = []
+
+    def visitAggregationFunction(self, expr):
+        ops = self.visitOperands(expr.operands)
+        idx = len(self.aggregateFunctions)
+        self.aggregateFunctions.append(expr.function)
+        self.aggregateInputs.append(ops[0])
+        return ColumnExpression(expr.function.name, self.groupExpressionCount + idx, expr.dataType)
+
+
+def rewriteAggregates(plan: "LogicalProjectionNode") -> Optional[LogicalNode]:
+    """RewriteAggregates.kt:19-50: Projection with aggregates -> Projection[finish](Aggregation(Projection[inputs])).
+    Non-aggregate select items are the (implicit) GROUP BY keys.  Returns None when there is no aggregate."""
+    if isinstance(plan.source, LogicalFilterNode) and _count_aggregates(plan.source.filter) > 0:
+        raise InvalidAggregatesException("Aggregate expressions not allowed in where clause")
+    classified = [(e, _count_aggregates(e)) for e in plan.expressions]
+    if sum(c for _, c in classified) == 0:
+        return None
+    groupCount = sum(1 for _, c in classified if c == 0)
+    rw = _RewriteAggregates(groupCount)
+    aggregateInput: List[Expression] = []
+    groupByFinish: List[Expression] = []
+    for expr, count in classified:
+        if count > 0:
+            groupByFinish.append(expr.accept(rw))
+        else:
+            index = len(aggregateInput)
+            aggregateInput.append(expr)
+            groupByFinish.append(ColumnExpression(f"_{index}", index, expr.dataType))
+    aggregateInput.extend(rw.aggregateInputs)
+    inp = LogicalProjectionNode(plan.source, tuple(aggregateInput))
+    aggregate = LogicalAggregationNode(inp, groupCount, tuple(rw.aggregateFunctions))
+    return LogicalProjectionNode(aggregate, tuple(groupByFinish))
+
+
 def buildLogicalPlan(tableRegistry: TableRegistry, query: Query) -> LogicalNode:
     """Planner.kt:19-28 for the shapes of the hot path."""
     if query.orderByColumn is not None:
@@ -93,14 +150,9 @@ def buildLogicalPlan(tableRegistry: TableRegistry, query: Query) -> LogicalNode:
     flt = typeCheck(query.filter.accept(resolver)) if query.filter is not None else None
     scan: LogicalNode = LogicalScanNode(query.from_, Schema(resolver.fields))
     source = LogicalFilterNode(scan, flt) if flt is not None else scan
-    aggs = [isinstance(e, AggregationFunctionExpression) for e in select]
-    if any(aggs):
-        # RewriteAggregates.kt:9-97 splits a projection with aggregates into pre-projection -> Aggregation ->
-        # post-projection; only the all-aggregate, no-group-by case stays on the GPU path
-        if not all(aggs):
-            raise NotImplementedError("GROUP BY / expressions over aggregates are outside the hot path (SURVEY 8f row 2)")
-        pre = LogicalProjectionNode(source, tuple(e.operands[0] for e in select))
-        return LogicalAggregationNode(pre, 0, tuple(e.function for e in select))
+    rewritten = rewriteAggregates(LogicalProjectionNode(source, tuple(select)))
+    if rewritten is not None:
+        return rewritten
     # Optimizer.kt:33-35 removes an identity projection over the scan
     if flt is None and all(isinstance(e, ColumnExpression) and e.index == i for i, e in enumerate(select)) \
             and len(select) == len(resolver.fields):
@@ -151,12 +203,24 @@ def buildPhysicalPlan(tableRegistry: TableRegistry, plan: LogicalNode, mode: Mod
             # FilterOperator returns the scan row itself (FilterOperator.kt:21): every scan column passes through
             identity = [ColumnExpression(f.name, i, f.type) for i, f in enumerate(scan.schema.fields)]
             return GpuFilterProjectOperator(ctx, _scan_of(tableRegistry, scan), flt, identity)
-    if isinstance(plan, LogicalAggregationNode) and plan.groupCount == 0 and isinstance(plan.source, LogicalProjectionNode):
+    if isinstance(plan, LogicalAggregationNode) and isinstance(plan.source, LogicalProjectionNode):
         m = _match_filter_scan(plan.source.source)
         if m is not None:
             flt, scan = m
-            return GpuGlobalAggregationOperator(ctx, _scan_of(tableRegistry, scan), flt, plan.source.expressions,
-                                                plan.aggregateFunctions)
+            exprs = plan.source.expressions
+            if plan.groupCount == 0:   # Planner.kt:56-58
+                return GpuGlobalAggregationOperator(ctx, _scan_of(tableRegistry, scan), flt, exprs, plan.aggregateFunctions)
+            return GpuGroupByAggregationOperator(ctx, _scan_of(tableRegistry, scan), flt, exprs[:plan.groupCount],
+                                                 exprs[plan.groupCount:], plan.aggregateFunctions)   # Planner.kt:54-55
+    if isinstance(plan, LogicalProjectionNode) and isinstance(plan.source, LogicalAggregationNode):
+        agg = plan.source
+        source = buildPhysicalPlan(tableRegistry, agg, mode, ctx)
+        from .datatypes import DataType
+        types = [e.dataType for e in agg.source.expressions[:agg.groupCount]] + [DataType.DOUBLE] * len(agg.aggregateFunctions)
+        if all(isinstance(e, ColumnExpression) and e.index == i for i, e in enumerate(plan.expressions)) \
+                and len(plan.expressions) == len(types):
+            return source                     # identity finish projection (Optimizer.kt:33-35)
+        return GpuFinishProjectionOperator(ctx, source, types, plan.expressions)
     raise NotImplementedError(f"plan shape outside the GPU hot path: {plan!r}")
 
 

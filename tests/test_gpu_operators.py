@@ -109,3 +109,63 @@ def test_global_aggregates_match_oracle(gpu_ctx, oracle):
                 # SUM / AVG: fixed-shape tree vs the reference's sequential order; bound n * eps * sum|x|
                 assert abs(g - w) <= 1e-9 * max(1.0, abs(w)), (g, w)
     batch.free()
+
+
+def test_query_test_group_by_multiple_columns(gpu_ctx):
+    """The reference's only end-to-end test (T/evaluator/QueryTest.kt:15-30) through query()."""
+    schema = Schema([Field("foo", S), Field("bar", S), Field("num", D)])
+    t = ColumnarTable.from_rows(schema, [["a", "A", 1.0], ["a", "B", 2.0], ["a", "B", 3.0], ["b", "B", 4.0],
+                                         ["b", "B", None], ["c", None, None]])
+    actual = query("table", "SELECT bar, SUM(num), foo FROM table", Mode.GPU_FUSED, table=t, ctx=gpu_ctx)
+    assert actual == [["A", 1.0, "a"], ["B", 5.0, "a"], ["B", 4.0, "b"], [None, None, "c"]]
+
+
+def test_main_kt_orders_example(gpu_ctx):
+    """Main.kt:29-50 (derived): SELECT SUM(net_price+net_shipping_cost)*1.25, country FROM orders -> CH 62.5, AT 131.25,
+    DE 456.25 (the reference adds ORDER BY 1, which is outside the path: compared as a set here)."""
+    schema = Schema([Field("id", S), Field("country", S), Field("net_price", D), Field("net_shipping_cost", D)])
+    rows = [["1", "DE", 100.0, 5.0], ["2", "DE", 200.0, 10.0], ["3", "AT", 100.0, 5.0], ["4", "CH", 40.0, 10.0], ["5", "DE", 50.0, 0.0]]
+    t = ColumnarTable.from_rows(schema, rows)
+    actual = query("orders", "SELECT SUM(net_price + net_shipping_cost) * 1.25, country FROM orders", Mode.GPU_FUSED, table=t, ctx=gpu_ctx)
+    assert sorted(actual) == [[62.5, "CH"], [131.25, "AT"], [456.25, "DE"]]
+    # insertion order of the groups: DE first
+    assert [r[1] for r in actual] == ["DE", "AT", "CH"]
+    # COUNT keeps the reference's Int (Accumulators.kt:26-36), expressions over aggregates run on the GPU
+    actual = query("orders", "SELECT country, COUNT(id), MAX(net_price) / MIN(net_price) FROM orders WHERE net_price > 45", Mode.GPU_FUSED,
+                   table=t, ctx=gpu_ctx)
+    assert actual == [["DE", 3, 4.0], ["AT", 1, 1.0]]
+
+
+def test_group_by_matches_oracle(gpu_ctx, oracle):
+    """Dictionary + boolean keys with nulls, every accumulator, a filter; 200k rows; groups in insertion order."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(5)
+    n = 200_000
+    d = ["k%03d" % i for i in range(37)]
+    s = Column(S, rng.integers(0, len(d), n).astype(np.int32), rng.random(n) > 0.05, d)
+    p = Column(B, rng.random(n) > 0.5, rng.random(n) > 0.1)
+    x = Column(D, np.round(rng.normal(0, 100, n)), rng.random(n) > 0.2)        # integer-valued: exact sums in any order
+    y = Column(I64, rng.integers(-1000, 1000, n))
+    Sx, P, X, Y = ColumnExpression("s", 0, S), ColumnExpression("p", 1, B), ColumnExpression("x", 2, D), ColumnExpression("y", 3, I64)
+    keys = [Sx, P]
+    exprs = [X, X, X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)]
+    aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
+    flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
+    batch = E.DeviceBatch.from_columns(gpu_ctx, [s, p, x, y])
+    for f in (None, flt):
+        res = E.filter_groupby(gpu_ctx, batch, gpu_ctx.compile(f) if f is not None else None,
+                               [gpu_ctx.compile(k) for k in keys], [gpu_ctx.compile(e) for e in exprs], aggs)
+        cols = res.to_columns()
+        got = [[c.value(i) for c in cols] for i in range(res.count)]
+        res.free()
+        want = oracle.filter_groupby([s, p, x, y], f, keys, exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert len(got) == len(want) and len(got) > 100
+        for g, w in zip(got, want):
+            assert g[:2] == w[:2]                      # same groups, same (insertion) order
+            for a, b, fn in zip(g[2:], w[2:], aggs):
+                if b is None or fn != oracle.AVG:
+                    assert a == b, (g, w)
+                else:
+                    assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+    batch.free()

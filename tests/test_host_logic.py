@@ -98,11 +98,14 @@ def test_logical_plan_shapes_and_column_slot_order():
     # distinct plain columns are an identity projection over the pruned scan: removed (Optimizer.kt:33-35)
     ident = buildLogicalPlan(r, parseQuery("SELECT b, a FROM t"))
     assert isinstance(ident, LogicalScanNode) and [f.name for f in ident.schema.fields] == ["b", "a"]
-    agg = buildLogicalPlan(r, parseQuery("SELECT SUM(a + 10*b), COUNT(c) FROM t WHERE c < 0.5"))
-    assert isinstance(agg, LogicalAggregationNode) and agg.groupCount == 0
+    fin = buildLogicalPlan(r, parseQuery("SELECT SUM(a + 10*b), COUNT(c) FROM t WHERE c < 0.5"))
+    agg = fin.source
+    assert isinstance(fin, LogicalProjectionNode) and isinstance(agg, LogicalAggregationNode) and agg.groupCount == 0
     assert agg.aggregateFunctions == (AggregationFunction.SUM, AggregationFunction.COUNT)
+    grouped = buildLogicalPlan(r, parseQuery("SELECT s, SUM(a) FROM t"))       # implicit GROUP BY s
+    assert grouped.source.groupCount == 1 and isinstance(grouped.source.source.source, LogicalScanNode)
     with pytest.raises(NotImplementedError):
-        buildLogicalPlan(r, parseQuery("SELECT s, SUM(a) FROM t"))
+        buildLogicalPlan(r, parseQuery("SELECT a FROM t ORDER BY 1"))
 
 
 # ---- serialisation + verification through the C ABI (planning-only context: no GPU needed) ------------------------
@@ -185,3 +188,28 @@ def test_column_type_mismatch_is_rejected(plan_ctx):
     assert ei.value.code == 2
     with pytest.raises(N.QeError):
         E.generated_source(plan_ctx, batch, None, [plan_ctx.compile(ColumnExpression("a", 5, I64))])
+
+
+def test_rewrite_aggregates_reference_fixtures():
+    """The three plan-shape fixtures of T/evaluator/RewriteAggregatesTest.kt:13-100."""
+    from queryengine_amd.planner import InvalidAggregatesException, rewriteAggregates
+    AF, AFE, CE = AggregationFunction, AggregationFunctionExpression, ColumnExpression
+    scan = LogicalScanNode("table", Schema([Field("foo", D)]))
+    got = rewriteAggregates(LogicalProjectionNode(scan, (AFE(AF.SUM, [CE("foo", 0, D)], D),)))
+    assert got == LogicalProjectionNode(
+        LogicalAggregationNode(LogicalProjectionNode(scan, (CE("foo", 0, D),)), 0, (AF.SUM,)), (CE("SUM", 0, D),))
+    scan2 = LogicalScanNode("table", Schema([Field("foo", D), Field("bar", D)]))
+    got = rewriteAggregates(LogicalProjectionNode(scan2, (AFE(AF.SUM, [CE("foo", 0, D)], D), AFE(AF.COUNT, [CE("bar", 1, D)], D),
+                                                          AFE(AF.AVG, [CE("foo", 0, D)], D))))
+    assert got == LogicalProjectionNode(
+        LogicalAggregationNode(LogicalProjectionNode(scan2, (CE("foo", 0, D), CE("bar", 1, D), CE("foo", 0, D))), 0,
+                               (AF.SUM, AF.COUNT, AF.AVG)),
+        (CE("SUM", 0, D), CE("COUNT", 1, D), CE("AVG", 2, D)))
+    div = FunctionExpression(Fn.DIV, [AFE(AF.COUNT, [CE("bar", 1, D)], D), AFE(AF.COUNT, [CE("foo", 0, D)], D)], D)
+    got = rewriteAggregates(LogicalProjectionNode(scan2, (div,)))
+    assert got == LogicalProjectionNode(
+        LogicalAggregationNode(LogicalProjectionNode(scan2, (CE("bar", 1, D), CE("foo", 0, D))), 0, (AF.COUNT, AF.COUNT)),
+        (FunctionExpression(Fn.DIV, [CE("COUNT", 0, D), CE("COUNT", 1, D)], D),))
+    assert rewriteAggregates(LogicalProjectionNode(scan2, (CE("foo", 0, D),))) is None
+    with pytest.raises(InvalidAggregatesException):
+        rewriteAggregates(LogicalProjectionNode(scan2, (AFE(AF.SUM, [AFE(AF.SUM, [CE("foo", 0, D)], D)], D),)))

@@ -129,3 +129,17 @@ def test_generator_is_counter_based(oracle):
     hi, _ = oracle.generate(s, 42, 400, 600, np.int64)
     assert np.array_equal(whole, np.concatenate([lo, hi]))
     assert whole.min() >= 0 and whole.max() < 1000
+
+
+def test_query_test_group_by_multiple_columns(oracle):
+    """T/evaluator/QueryTest.kt:15-30: SELECT bar, SUM(num), foo FROM table -- implicit GROUP BY (bar, foo), nulls in
+    keys and values, insertion-ordered groups.  The aggregation operator yields [bar, foo, SUM]; the finish
+    projection re-orders to [bar, SUM, foo]."""
+    S, D = DataType.STRING, DataType.DOUBLE
+    rows = [["a", "A", 1.0], ["a", "B", 2.0], ["a", "B", 3.0], ["b", "B", 4.0], ["b", "B", None], ["c", None, None]]
+    cols = [Column.from_values(t, [r[j] for r in rows]) for j, t in enumerate((S, S, D))]
+    for mode in MODES:
+        out = oracle.filter_groupby(cols, None, [ColumnExpression("bar", 1, S), ColumnExpression("foo", 0, S)],
+                                    [ColumnExpression("num", 2, D)], [oracle.SUM], mode)
+        finished = [[bar, s, foo] for bar, foo, s in out]
+        assert finished == [["A", 1.0, "a"], ["B", 5.0, "a"], ["B", 4.0, "b"], [None, None, "c"]]
