@@ -466,7 +466,8 @@ int32_t qe_stream_read_write_time(qe_ctx *ctx, int64_t nbytes, int32_t write_eve
         for (int r = 0; r <= reps; r++) {
             QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
             launch_stream_read_write(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8), dst, dst_bytes,
-                                     write_every % 1000, ((write_every / 1000) % 10000) * 100, (write_every / 10000000) * 100);
+                                     write_every % 1000, ((write_every / 1000) % 10000) * 100, (write_every / 10000000) * 100,
+                                     std::getenv("QE_CALIB_BLOCKS") ? std::atoi(std::getenv("QE_CALIB_BLOCKS")) : 1);
             QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
             QE_HIP(hipStreamSynchronize(ctx->stream));
             float ms = 0.f;

@@ -16,6 +16,6 @@ void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned
 
 // read stream + a trickle of writes (one 512-byte block per wave every `write_every` read iterations of 8 KiB)
 void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, void *dst,
-                              int64_t dst_bytes, int write_every, int window_period, int window_len);
+                              int64_t dst_bytes, int write_every, int window_period, int window_len, int blocks_per_event);
 
 }  // namespace qe

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const u64x2 *src, i64 
 // `write_every`-th iteration each wave also stores one 512-byte block (8 B per lane) to a private,
 // sequential position of `dst`.
 __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src, i64 nvec, u64 *sink, u64 *dst, i64 dst_words_per_wave,
-                                                                int write_every, int window_period, int window_len) {
+                                                                int write_every, int window_period, int window_len, int blocks_per_event) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src
         for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y;
-        if (write_every > 0 && it % write_every == 0) pending++;
+        if (write_every > 0 && it % (write_every * blocks_per_event) == 0) pending += blocks_per_event;   // same bytes, longer runs
         // window_period == 0: write at once (a trickle).  Otherwise every wave of the device holds its blocks
         // until the shared 100 MHz clock says the write window is open, so that writes reach HBM in bursts.
         bool open = true;
@@ -153,13 +153,13 @@ __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src
 }
 
 void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, void *dst,
-                              int64_t dst_bytes, int write_every, int window_period, int window_len) {
+                              int64_t dst_bytes, int write_every, int window_period, int window_len, int blocks_per_event) {
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
     const int grid = 256 * 8;
     const i64 waves = (i64)grid * 4;
     hipLaunchKernelGGL(stream_read_write_kernel, dim3(grid), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink, (u64 *)dst,
-                       (i64)(dst_bytes / 8 / waves), write_every, window_period, window_len);
+                       (i64)(dst_bytes / 8 / waves), write_every, window_period, window_len, blocks_per_event < 1 ? 1 : blocks_per_event);
 }
 
 void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink) {

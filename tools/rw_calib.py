@@ -14,3 +14,9 @@ for period_us, len_us in ((50, 5), (100, 5), (100, 10), (200, 10), (200, 20), (4
         code = we + 1000 * period_us + 10000000 * len_us
         ms, wb = ctx.stream_read_write_time(n, code, 5)
         print(f"write_every {we} window {len_us} us every {period_us} us: {ms:.3f} ms  written {wb/1e9:.3f} GB")
+
+# same written bytes, longer contiguous runs per write event (QE_CALIB_BLOCKS x 512 B every QE_CALIB_BLOCKS-th time)
+for blocks in (1, 4, 16, 64):
+    os.environ["QE_CALIB_BLOCKS"] = str(blocks)
+    ms, wb = ctx.stream_read_write_time(n, 2, 5)
+    print(f"write 0.8 GB as runs of {blocks * 512} B per wave: {ms:.3f} ms")
