@@ -531,10 +531,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.cmp_semantics = ctx->opts.cmp_semantics;
     in.geo = geometry_of(ctx);
     in.nontemporal = ctx->opts.tuning[2] % 10 == 2 ? 0 : 1;
+    in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
     in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -564,7 +565,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         for (const OutSpec &o : plan->cg.outs)
             rowbytes += (o.type == QE_BOOLEAN ? 1 : (o.type == QE_DOUBLE || o.type == QE_INT64) ? 8 : 4) + (o.nullable ? 1 : 0);
         rowbytes = std::max<size_t>(rowbytes, 1);
-        if (ctx->opts.tuning[7] / 100 == 0) in.geo.nbuf = rowbytes <= 16 ? 3 : 2;
+        if (ctx->opts.tuning[7] / 100 == 0) in.geo.nbuf = 2;
         if (ctx->opts.tuning[0] == 0) {
             const size_t limit = 96 * 1024;
             while (in.geo.threads > 64 && (size_t)(in.geo.threads / 64) * in.geo.nbuf * in.geo.ring_entries * rowbytes > limit)

@@ -148,8 +148,8 @@ struct FusedGeometry {
     int threads = 256;
     int rows_per_lane = 2;
     int unroll = 8;          // load groups (of 128 rows) per sub-tile
-    int subs_per_chunk = 4;  // sub-tiles per chunk (one ticket + one look-back per chunk)
-    int nbuf = 3;            // LDS buffers per wave = depth of the FIFO of streamed-but-unresolved chunks + 1
+    int subs_per_chunk = 16; // sub-tiles per chunk (one ticket + one look-back per chunk)
+    int nbuf = 2;            // LDS buffers per wave = depth of the FIFO of streamed-but-unresolved chunks + 1
     int ring_entries = 256;  // LDS entries per wave, buffer and output column: a chunk's kept rows stay in LDS
                              // until it is resolved; only an overflow spills to the global staging slot
     int lookback_k = 1;      // descriptor windows (of 64) loaded per look-back round
@@ -174,6 +174,7 @@ struct CodegenInput {
     int cmp_semantics = QE_CMP_TOTAL_ORDER;
     FusedGeometry geo;
     int nontemporal = 1;
+    int nt_stores = 1;    // non-temporal stores for the output rows
     int debug_mask = 0;   // ablation builds (wrong results): 1 no look-back, 2 no staging stores, 4 no move
 };
 

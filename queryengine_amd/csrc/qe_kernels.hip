@@ -2,6 +2,7 @@
 // the synthetic column generator, byte->bitmap packing of nullable/boolean
 // outputs, and the streaming-read calibration kernel used for the roofline.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "qe_kernels.h"
 
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const u64x2 *src, i64 
 // `write_every`-th iteration each wave also stores one 512-byte block (8 B per lane) to a private,
 // sequential position of `dst`.
 __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src, i64 nvec, u64 *sink, u64 *dst, i64 dst_words_per_wave,
-                                                                int write_every, int window_period, int window_len, int blocks_per_event) {
+                                                                int write_every, int window_period, int window_len, int blocks_per_event, int store_kind) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -140,7 +141,10 @@ __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src
         if (window_period > 0) open = (__builtin_amdgcn_s_memrealtime() % (u64)window_period) < (u64)window_len;
         if (pending > 0 && open) {
             for (; pending > 0 && wpos + 64 <= dst_words_per_wave; --pending) {
-                out[wpos + lane] = acc + pending;
+                if (store_kind == 1) __builtin_nontemporal_store(acc + pending, out + wpos + lane);
+                else if (store_kind == 2) __hip_atomic_store(out + wpos + lane, acc + pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (store_kind == 3) __hip_atomic_store(out + wpos + lane, acc + pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else out[wpos + lane] = acc + pending;
                 wpos += 64;
             }
         }
@@ -154,12 +158,13 @@ __global__ void __launch_bounds__(256) stream_read_write_kernel(const u64x2 *src
 
 void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, void *dst,
                               int64_t dst_bytes, int write_every, int window_period, int window_len, int blocks_per_event) {
+    const int store_kind = getenv("QE_CALIB_STORE") ? atoi(getenv("QE_CALIB_STORE")) : 0;
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
     const int grid = 256 * 8;
     const i64 waves = (i64)grid * 4;
     hipLaunchKernelGGL(stream_read_write_kernel, dim3(grid), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink, (u64 *)dst,
-                       (i64)(dst_bytes / 8 / waves), write_every, window_period, window_len, blocks_per_event < 1 ? 1 : blocks_per_event);
+                       (i64)(dst_bytes / 8 / waves), write_every, window_period, window_len, blocks_per_event < 1 ? 1 : blocks_per_event, store_kind);
 }
 
 void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink) {
