@@ -87,10 +87,16 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: queryengine_amd has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    rehearsal = os.environ.get("QE_BENCH_REHEARSAL") == "1"   # N ranks sharing GPU 0 over gloo: exercises the N>1 code on a 1-GPU box
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from queryengine_amd import engine as E
     from queryengine_amd import native as N
@@ -137,8 +143,8 @@ def main():
     dt = time.perf_counter() - t0
     _, kernel_ms_total, launches = ctx.kernel_time()
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([nout], dtype=torch.int64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    cnt = torch.tensor([nout], dtype=torch.int64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)

@@ -123,6 +123,167 @@ def gather_result(result, dst: int = 0, group=None):
     return out if dist.get_rank(group) == dst else None
 
 
+# ---- aggregation across shards ("Cross-GPU: reduce of the per-GPU partials") -------------------
+_MIN, _MAX, _SUM, _COUNT, _AVG = 0, 1, 2, 3, 4     # ast/Functions.kt:24-26
+
+
+def expand_partial_aggregates(aggs: Sequence[int]):
+    """Per-shard accumulators that can be merged: AVG becomes SUM + COUNT of the same input (Accumulators.kt:82-107 keeps
+    exactly that pair).  Returns (partial_fns, source_index per partial, recipe) where recipe[i] lists the partial slots
+    of aggregate i."""
+    fns: List[int] = []
+    src: List[int] = []
+    recipe: List[Tuple[int, ...]] = []
+    for i, a in enumerate(aggs):
+        a = int(a)
+        if a == _AVG:
+            recipe.append((len(fns), len(fns) + 1))
+            fns += [_SUM, _COUNT]
+            src += [i, i]
+        else:
+            recipe.append((len(fns),))
+            fns.append(a)
+            src.append(i)
+    return fns, src, recipe
+
+
+def _java_min(a: float, b: float) -> float:
+    """java.lang.Math.min: NaN wins, -0.0 < 0.0."""
+    if a != a or b != b:
+        return float("nan")
+    if a == 0.0 and b == 0.0:
+        return a if np.signbit(a) else b
+    return a if a < b else b
+
+
+def _java_max(a: float, b: float) -> float:
+    if a != a or b != b:
+        return float("nan")
+    if a == 0.0 and b == 0.0:
+        return b if np.signbit(a) else a
+    return a if a > b else b
+
+
+def _merge_partial(fn: int, acc: Optional[float], value: Optional[float]) -> Optional[float]:
+    if value is None:
+        return acc
+    if acc is None:
+        return value
+    if fn == _MIN:
+        return _java_min(acc, value)
+    if fn == _MAX:
+        return _java_max(acc, value)
+    return acc + value           # SUM, COUNT
+
+
+def finish_partials(aggs: Sequence[int], recipe, partial: Sequence[Optional[float]]) -> List[Optional[float]]:
+    """Partial slots -> final accumulator values (Accumulators.kt:26-107: empty => null, COUNT => count)."""
+    out: List[Optional[float]] = []
+    for a, slots in zip(aggs, recipe):
+        if int(a) == _AVG:
+            s, c = partial[slots[0]], partial[slots[1]]
+            out.append(None if not c or s is None else s / c)
+        elif int(a) == _COUNT:
+            out.append(partial[slots[0]] or 0.0)
+        else:
+            out.append(partial[slots[0]])
+    return out
+
+
+def combine_aggregate_partials(partial_fns: Sequence[int], per_rank: Sequence[Sequence[Optional[float]]]) -> List[Optional[float]]:
+    """Fold the shards' partials in RANK order (a fixed order: every rank computes the identical result)."""
+    acc: List[Optional[float]] = [None] * len(partial_fns)
+    for values in per_rank:
+        for j, fn in enumerate(partial_fns):
+            acc[j] = _merge_partial(fn, acc[j], values[j])
+    return acc
+
+
+def allreduce_aggregates(local: Sequence[Optional[float]], partial_fns: Sequence[int], group=None, device=None):
+    """All ranks contribute their partial accumulators ({value, valid} pairs, 16 B per aggregate) with one all-gather and
+    fold them in rank order.  MIN/MAX/COUNT are exact; SUM is the sum of the shards' sums (deterministic for a world size)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([[0.0 if v is None else float(v), 0.0 if v is None else 1.0] for v in local],
+                        dtype=torch.float64, device=device).reshape(-1, 2)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    per_rank = []
+    for p in parts:
+        h = p.cpu().numpy()
+        per_rank.append([float(h[j, 0]) if h[j, 1] != 0.0 else None for j in range(h.shape[0])])
+    return combine_aggregate_partials(partial_fns, per_rank)
+
+
+def sharded_filter_aggregate(ctx, batch, cf, exprs, aggs: Sequence[int], group=None):
+    """GlobalAggregation over a row-range sharded table: the fused filter+aggregate kernel on every rank's shard, then ONE
+    small all-gather.  `exprs` are CompiledExpressions (one per aggregate).  Returns the final values on every rank."""
+    import torch
+    from . import engine as E
+    fns, src, recipe = expand_partial_aggregates(aggs)
+    local, _ = E.filter_aggregate(ctx, batch, cf, [exprs[i] for i in src], fns)
+    merged = allreduce_aggregates(local, fns, group, device=torch.device("cuda", ctx.device))
+    return finish_partials(aggs, recipe, merged)
+
+
+def merge_group_partials(partial_fns: Sequence[int], per_rank_groups):
+    """Group-by across shards.  per_rank_groups[r] = list of (key tuple, [partial values]) in rank r's insertion order.
+    Shards are contiguous row ranges in rank order, so the global first occurrence of a key is in the lowest rank that
+    has it: walking the ranks in order and appending unseen keys reproduces the reference's LinkedHashMap order
+    (GroupByAggregationOperator.kt:22)."""
+    merged = {}
+    for groups in per_rank_groups:
+        for key, values in groups:
+            key = tuple(_nan_key(k) for k in key)
+            acc = merged.get(key)
+            if acc is None:
+                merged[key] = list(values)
+            else:
+                for j, fn in enumerate(partial_fns):
+                    acc[j] = _merge_partial(fn, acc[j], values[j])
+    return [(tuple(None if k is _NAN else k for k in key), acc) for key, acc in merged.items()]
+
+
+class _NaN:
+    def __repr__(self):
+        return "NaN"
+
+
+_NAN = _NaN()
+
+
+def _nan_key(k):
+    """Double.equals: all NaNs are one key (and -0.0 != 0.0, which Python's dict would merge -- keys here are
+    dictionary strings / booleans, floats only pass through for completeness)."""
+    if isinstance(k, float) and k != k:
+        return _NAN
+    return k
+
+
+def allgather_groups(local_groups, partial_fns: Sequence[int], group=None):
+    """Every rank receives every shard's (small) group table and merges in rank order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    tables = [None] * world
+    dist.all_gather_object(tables, local_groups, group=group)
+    return merge_group_partials(partial_fns, tables)
+
+
+def sharded_filter_groupby(ctx, batch, cf, keys, exprs, aggs: Sequence[int], group=None):
+    """GroupByAggregation over a sharded table: fused group-by kernel per shard, then one all-gather of the group tables.
+    Returns rows [key values..., aggregate values...] in global insertion order on every rank."""
+    from . import engine as E
+    fns, src, recipe = expand_partial_aggregates(aggs)
+    res = E.filter_groupby(ctx, batch, cf, keys, [exprs[i] for i in src], fns)
+    cols = res.to_columns()
+    res.free()
+    nk = len(keys)
+    local = [(tuple(c.value(i) for c in cols[:nk]), [c.value(i) for c in cols[nk:]]) for i in range(len(cols[0]) if cols else 0)]
+    merged = allgather_groups(local, fns, group)
+    return [list(k) + finish_partials(aggs, recipe, acc) for k, acc in merged]
+
+
 def time_gather(ctx, batch, cf, cp, world: int, rank: int, reps: int = 3):
     """bench.py --gather: time the materialising exchange separately from the scan."""
     import torch

@@ -11,6 +11,7 @@ There is no CPU evaluation here: expressions only ever run inside libqe_hip.so.
 """
 from __future__ import annotations
 
+import math
 from typing import Any, Callable, List, Optional, Sequence
 
 from . import engine as E
@@ -56,6 +57,48 @@ def mapTo(op: Operator, result: list, mapper: Callable[[List[Any]], Any]) -> lis
 
 def map(op: Operator, mapper: Callable[[List[Any]], Any]) -> list:   # noqa: A001 (reference name)
     return mapTo(op, [], mapper)
+
+
+def _compare_key(value: Any):
+    """Sort key with the order of Kotlin's ``compareValues`` on the boxed types of the engine: null first, then
+    ``Double.compareTo`` (total order: -0.0 < 0.0, NaN greatest), ``String.compareTo`` (UTF-16 code units),
+    ``Boolean.compareTo`` (false < true), integers numerically."""
+    if value is None:
+        return (0,)
+    if isinstance(value, bool):
+        return (1, int(value))
+    if isinstance(value, float):
+        if value != value:
+            return (1, 1, 0.0, 0)
+        return (1, 0, value, 0 if (value == 0.0 and math.copysign(1.0, value) < 0) else 1)
+    if isinstance(value, str):
+        return (1, value.encode("utf-16-be", "surrogatepass"))
+    return (1, 0, value, 1)
+
+
+class OrderByOperator(Operator):
+    """operator/OrderByOperator.kt:5-31: drain the source in ``open()``, stable ``sortBy`` on one column.
+
+    A host-side consumer of the path's output (sorting is not on the filter/project path); the rows
+    it sorts were produced by the GPU operators below it."""
+
+    def __init__(self, source: Operator, index: int):
+        self.source = source
+        self.index = index
+        self._iter = None
+
+    def open(self) -> None:
+        data = mapTo(self.source, [], lambda row: list(row))
+        data.sort(key=lambda row: _compare_key(row[self.index]))   # list.sort is stable, like java.util.List.sort
+        self._iter = iter(data)
+
+    def close(self) -> None:
+        self._iter = None
+
+    def next(self) -> Optional[List[Any]]:
+        if self._iter is None:
+            raise RuntimeError("Operator not opened")               # OrderByOperator.kt:23
+        return next(self._iter, None)
 
 
 class ColumnarScanOperator(Operator):

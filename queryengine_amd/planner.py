@@ -20,7 +20,7 @@ from .ast import (AggregationFunction, AggregationFunctionExpression, ColumnExpr
                   Expression, FunctionExpression, IdentifierExpression)
 from .datatypes import Field, Schema
 from .operators import (ColumnarScanOperator, GpuFilterProjectOperator, GpuFinishProjectionOperator,
-                        GpuGlobalAggregationOperator, GpuGroupByAggregationOperator, Operator)
+                        GpuGlobalAggregationOperator, GpuGroupByAggregationOperator, Operator, OrderByOperator)
 from .operators import map as op_map
 from .sql import Query, parseQuery
 from .table import Table, TableRegistry
@@ -57,6 +57,13 @@ class LogicalAggregationNode(LogicalNode):
     source: LogicalNode
     groupCount: int
     aggregateFunctions: tuple
+
+
+@dataclass(frozen=True)
+class LogicalOrderByNode(LogicalNode):
+    """evaluator/LogicalPlan.kt:12; ``index`` is the 1-based select position of ``ORDER BY n``."""
+    source: LogicalNode
+    index: int
 
 
 @dataclass(frozen=True)
@@ -140,9 +147,10 @@ def rewriteAggregates(plan: "LogicalProjectionNode") -> Optional[LogicalNode]:
 
 
 def buildLogicalPlan(tableRegistry: TableRegistry, query: Query) -> LogicalNode:
-    """Planner.kt:19-28 for the shapes of the hot path."""
+    """Planner.kt:8-28 for the shapes of the hot path; ORDER BY wraps the finished plan (Planner.kt:13)."""
     if query.orderByColumn is not None:
-        raise NotImplementedError("ORDER BY is outside the filter/project hot path (SURVEY 8f row 4)")
+        inner = buildLogicalPlan(tableRegistry, Query(query.select, query.from_, query.filter, None))
+        return LogicalOrderByNode(inner, query.orderByColumn)
     schema = tableRegistry.getSchema(query.from_)
     resolver = _ResolveSchema(schema)
     # rewritePlan visits the Projection before its source (ResolveSchema.kt:24-33): SELECT list first, then WHERE
@@ -191,6 +199,8 @@ def buildPhysicalPlan(tableRegistry: TableRegistry, plan: LogicalNode, mode: Mod
                       ctx: Optional[E.Context] = None) -> Operator:
     """Planner.kt:30-63 with the Filter/Projection(/global Aggregation) subtree fused into one GPU operator."""
     ctx = ctx or default_context(mode)
+    if isinstance(plan, LogicalOrderByNode):     # Planner.kt:58-61
+        return OrderByOperator(buildPhysicalPlan(tableRegistry, plan.source, mode, ctx), plan.index - 1)
     if isinstance(plan, LogicalProjectionNode):
         m = _match_filter_scan(plan.source)
         if m is not None:

@@ -164,3 +164,32 @@ class ExprGen:
 
     def _dict_of(self, c):
         return self.dicts.get(c.name, ["k0000"])
+
+
+# ---- a sharded aggregation case: every value is a function of the GLOBAL row index -----------------------------------
+_AGG_DICT = [f"k{i:02d}" for i in range(12)]
+
+
+def agg_case_columns(begin: int, end: int) -> List[Column]:
+    """Columns s (STRING, nullable, keys k06.. appear only in the second half of a 30 000-row table), p (BOOLEAN),
+    x (INT64), y (DOUBLE with nulls, integer valued: sums are exact in any order)."""
+    i = np.arange(begin, end, dtype=np.int64)
+    h = (i * 2654435761) % 1000003
+    code = np.where(i < 15000, h % 6, h % 12).astype(np.int32)
+    s_valid = (h % 17) != 0
+    p = (h % 3) == 0
+    x = (h % 1000).astype(np.int64)
+    y = ((h % 2001) - 1000).astype(np.float64)
+    y_valid = (h % 11) != 0
+    return [Column(S, code, s_valid, list(_AGG_DICT)), Column(B, p, None), Column(I64, x, None), Column(D, y, y_valid)]
+
+
+def AGG_CASE():
+    """(filter, group keys, aggregate inputs, aggregate functions) over agg_case_columns."""
+    from queryengine_amd import AggregationFunction as AF
+    s, p, x, y = col("s", 0, S), col("p", 1, B), col("x", 2, I64), col("y", 3, D)
+    flt = fn(Fn.CMP_LT, x, num(900))
+    keys = [s, p]
+    exprs = [y, y, fn(Fn.ADD, x, y), x, y]
+    aggs = [int(AF.MIN), int(AF.MAX), int(AF.SUM), int(AF.COUNT), int(AF.AVG)]
+    return flt, keys, exprs, aggs

@@ -101,3 +101,54 @@ def test_sharded_filter_project_gather_matches_single_process(oracle):
         assert np.array_equal(gv.astype(bool), wv)
         assert np.array_equal(g[wv].view(np.uint64), w.data[wv].view(np.uint64))
     assert np.array_equal(empty_case, np.arange(3))
+
+
+def _agg_worker(rank, world, port, nrows, q):
+    """Each rank aggregates its shard with the oracle (standing in for the absent GPU) and merges across ranks."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import qe_oracle as O
+        from queryengine_amd import distributed as D
+        from helpers import agg_case_columns, AGG_CASE
+        begin, end = D.shard_range(nrows, rank, world)
+        cols = agg_case_columns(begin, end)
+        flt, keys, exprs, aggs = AGG_CASE()
+        fns, src, recipe = D.expand_partial_aggregates(aggs)
+        local, _ = O.filter_aggregate(cols, flt, [exprs[i] for i in src], fns, O.BYTECODE_COMPILER)
+        merged = D.finish_partials(aggs, recipe, D.allreduce_aggregates(local, fns))
+        rows = O.filter_groupby(cols, flt, keys, [exprs[i] for i in src], fns, O.BYTECODE_COMPILER)
+        groups = D.allgather_groups([(tuple(r[:len(keys)]), list(r[len(keys):])) for r in rows], fns)
+        grouped = [list(k) + D.finish_partials(aggs, recipe, acc) for k, acc in groups]
+        q.put((rank, merged, grouped))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_aggregation_merges_to_the_single_process_result(oracle):
+    """SURVEY 8f rows 1-2 across shards: MIN/MAX/SUM/COUNT/AVG partials merged in rank order equal the whole-table
+    accumulators (the sums are integers < 2^53: exact), groups come out in GLOBAL insertion order."""
+    from helpers import agg_case_columns, AGG_CASE
+    world, nrows = 2, 30_000
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agg_worker, args=(r, world, port, nrows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cols = agg_case_columns(0, nrows)
+    flt, keys, exprs, aggs = AGG_CASE()
+    want, _ = oracle.filter_aggregate(cols, flt, exprs, aggs, oracle.BYTECODE_COMPILER)
+    want_groups = oracle.filter_groupby(cols, flt, keys, exprs, aggs, oracle.BYTECODE_COMPILER)
+    assert len(want_groups) > 3 and any(r[0] is None for r in want_groups)
+    for _, merged, grouped in got:
+        assert merged == want
+        assert grouped == want_groups

@@ -45,6 +45,18 @@ def test_result_views_and_gather_world1(gpu_ctx, oracle):
             if gv is not None:
                 assert np.array_equal(gv.cpu().numpy().astype(bool), hv)
             assert np.array_equal(g.cpu().numpy()[hv].view(np.uint64), h.data[hv].view(np.uint64))
+        # aggregation across shards (here one): AVG is carried as SUM + COUNT partials and finished after the merge
+        from helpers import AGG_CASE, agg_case_columns
+        from queryengine_amd.distributed import sharded_filter_aggregate, sharded_filter_groupby
+        cols = agg_case_columns(0, 30_000)
+        flt, keys, exprs, aggs = AGG_CASE()
+        ab = E.DeviceBatch.from_columns(gpu_ctx, cols)
+        cf, ck, ce = gpu_ctx.compile(flt), [gpu_ctx.compile(k) for k in keys], [gpu_ctx.compile(e) for e in exprs]
+        want, _ = oracle.filter_aggregate(cols, flt, exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert sharded_filter_aggregate(gpu_ctx, ab, cf, ce, aggs) == want
+        assert sharded_filter_groupby(gpu_ctx, ab, cf, ck, ce, aggs) == oracle.filter_groupby(cols, flt, keys, exprs, aggs,
+                                                                                              oracle.BYTECODE_COMPILER)
+        ab.free()
     finally:
         dist.destroy_process_group()
     res.free()

@@ -122,12 +122,17 @@ def test_query_test_group_by_multiple_columns(gpu_ctx):
 
 def test_main_kt_orders_example(gpu_ctx):
     """Main.kt:29-50 (derived): SELECT SUM(net_price+net_shipping_cost)*1.25, country FROM orders -> CH 62.5, AT 131.25,
-    DE 456.25 (the reference adds ORDER BY 1, which is outside the path: compared as a set here)."""
+    DE 456.25 in the order of ORDER BY 1 (OrderByOperator.kt:9-12 on top of the GPU operators)."""
     schema = Schema([Field("id", S), Field("country", S), Field("net_price", D), Field("net_shipping_cost", D)])
     rows = [["1", "DE", 100.0, 5.0], ["2", "DE", 200.0, 10.0], ["3", "AT", 100.0, 5.0], ["4", "CH", 40.0, 10.0], ["5", "DE", 50.0, 0.0]]
     t = ColumnarTable.from_rows(schema, rows)
     actual = query("orders", "SELECT SUM(net_price + net_shipping_cost) * 1.25, country FROM orders", Mode.GPU_FUSED, table=t, ctx=gpu_ctx)
     assert sorted(actual) == [[62.5, "CH"], [131.25, "AT"], [456.25, "DE"]]
+    ordered = query("orders", "SELECT SUM(net_price + net_shipping_cost) * 1.25, country FROM orders ORDER BY 1", Mode.GPU_FUSED,
+                    table=t, ctx=gpu_ctx)
+    assert ordered == [[62.5, "CH"], [131.25, "AT"], [456.25, "DE"]]
+    ordered = query("orders", "SELECT id, net_price FROM orders WHERE net_price >= 50 ORDER BY 2", Mode.GPU_FUSED, table=t, ctx=gpu_ctx)
+    assert ordered == [["5", 50.0], ["1", 100.0], ["3", 100.0], ["2", 200.0]]      # stable: id 1 before id 3
     # insertion order of the groups: DE first
     assert [r[1] for r in actual] == ["DE", "AT", "CH"]
     # COUNT keeps the reference's Int (Accumulators.kt:26-36), expressions over aggregates run on the GPU

@@ -10,7 +10,8 @@ from queryengine_amd import (BooleanLiteralExpression, Column, ColumnExpression,
                              StringLiteralExpression, TableRegistry, AggregationFunctionExpression, AggregationFunction)
 from queryengine_amd import engine as E
 from queryengine_amd import native as N
-from queryengine_amd.planner import (LogicalAggregationNode, LogicalFilterNode, LogicalProjectionNode, LogicalScanNode,
+from queryengine_amd.planner import (LogicalAggregationNode, LogicalFilterNode, LogicalOrderByNode, LogicalProjectionNode,
+                                     LogicalScanNode,
                                      SchemaException, buildLogicalPlan)
 from queryengine_amd.program import serialize
 from queryengine_amd.sql import SyntaxException, parseExpression, parseQuery
@@ -104,8 +105,46 @@ def test_logical_plan_shapes_and_column_slot_order():
     assert agg.aggregateFunctions == (AggregationFunction.SUM, AggregationFunction.COUNT)
     grouped = buildLogicalPlan(r, parseQuery("SELECT s, SUM(a) FROM t"))       # implicit GROUP BY s
     assert grouped.source.groupCount == 1 and isinstance(grouped.source.source.source, LogicalScanNode)
-    with pytest.raises(NotImplementedError):
-        buildLogicalPlan(r, parseQuery("SELECT a FROM t ORDER BY 1"))
+    ordered = buildLogicalPlan(r, parseQuery("SELECT a + b, c FROM t WHERE a < 100 ORDER BY 2"))   # Planner.kt:13
+    assert isinstance(ordered, LogicalOrderByNode) and ordered.index == 2
+    assert isinstance(ordered.source, LogicalProjectionNode) and isinstance(ordered.source.source, LogicalFilterNode)
+    ordered = buildLogicalPlan(r, parseQuery("SELECT s, SUM(a) FROM t ORDER BY 1"))    # RewriteAggregates.kt:50-53
+    assert isinstance(ordered.source.source, LogicalAggregationNode)
+
+
+def test_order_by_operator_follows_compare_values():
+    """OrderByOperator.kt:9-12: stable sortBy { row[index] as Comparable } = compareValues: null first, then
+    Double.compareTo (-0.0 < 0.0, NaN last), String.compareTo (UTF-16 code units), Boolean false < true."""
+    from queryengine_amd.operators import Operator, OrderByOperator, map as op_map
+
+    class Rows(Operator):
+        def __init__(self, rows):
+            self.rows, self.i = rows, None
+
+        def open(self):
+            self.i = 0
+
+        def close(self):
+            self.i = None
+
+        def next(self):
+            if self.i >= len(self.rows):
+                return None
+            self.i += 1
+            return self.rows[self.i - 1]
+
+    nan = float("nan")
+    rows = [[1.0, "a"], [nan, "b"], [None, "c"], [-0.0, "d"], [0.0, "e"], [float("inf"), "f"], [None, "g"], [-1.0, "h"], [0.0, "i"]]
+    op = OrderByOperator(Rows(rows), 0)
+    assert [r[1] for r in op_map(op, lambda r: r)] == ["c", "g", "h", "d", "e", "i", "a", "f", "b"]
+    assert [r[1] for r in op_map(op, lambda r: r)] == ["c", "g", "h", "d", "e", "i", "a", "f", "b"]   # re-openable
+    with pytest.raises(RuntimeError):
+        op.next()
+    # U+FF5E (one code unit 0xFF5E) sorts AFTER U+1F600 (surrogates 0xD83D 0xDE00) in UTF-16 order, before it by code point
+    strs = [["\uff5e"], ["\U0001F600"], ["B"], [None], ["a"], [""]]
+    assert op_map(OrderByOperator(Rows(strs), 0), lambda r: r[0]) == [None, "", "B", "a", "\U0001F600", "\uff5e"]
+    bools = [[True], [None], [False]]
+    assert op_map(OrderByOperator(Rows(bools), 0), lambda r: r[0]) == [None, False, True]
 
 
 # ---- serialisation + verification through the C ABI (planning-only context: no GPU needed) ------------------------
