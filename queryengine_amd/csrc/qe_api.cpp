@@ -497,8 +497,10 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     if (u >= 1 && u <= 16) g.unroll = u;
     const int spc = ctx->opts.tuning[4];
     if (spc >= 1 && spc <= 4096) g.subs_per_chunk = spc;
-    const int lbk = ctx->opts.tuning[6];
+    const int lbk = ctx->opts.tuning[6] % 100;   // tuning[6] = lookback_k + 100 * gate_period_log2 + 10000 * gate_width_log2
     if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
+    const int gp = (ctx->opts.tuning[6] / 100) % 100, gw = ctx->opts.tuning[6] / 10000;
+    if (gp >= 8 && gp <= 24 && gw >= 4 && gw < gp) { g.gate_period_log2 = gp; g.gate_width_log2 = gw; }
     const int pm = ctx->opts.tuning[2] / 10;   // tuning[2] = 10 * (prio_mode + 1) + nt ; 0 = default
     if (pm >= 1 && pm <= 3) g.prio_mode = pm - 1;
     const int nb = ctx->opts.tuning[7] / 100;   // tuning[7] = 100 * nbuf + (stagger / resolve_at code)
@@ -535,7 +537,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.debug_mask = ctx->opts.tuning[5];
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "k" << in.geo.lookback_k << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -967,8 +969,9 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         const int64_t G = cg.ngroups;
         const int W = cg.table_words;
         // global accumulator table, initialised from the host (smallest row = ~0, MIN/MAX keys at their identity)
-        std::vector<unsigned long long> tab((size_t)G * W);
-        for (int64_t g = 0; g < G; g++) {
+        const int copies = cg.table_copies;
+        std::vector<unsigned long long> tab((size_t)G * W * copies);
+        for (int64_t g = 0; g < G * copies; g++) {
             unsigned long long *e = &tab[(size_t)g * W];
             e[0] = ~0ull;
             for (int i = 0; i < nagg; i++) {
@@ -993,6 +996,30 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         QE_HIP(hipMemcpyAsync(tab.data(), d_tab, tab.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         QE_HIP(hipStreamSynchronize(ctx->stream));
         if (n > 0) collect_time(ctx);
+        // fold the per-XCD copies into copy 0, in XCD order
+        for (int c = 1; c < copies; c++) {
+            for (int64_t g = 0; g < G; g++) {
+                unsigned long long *d = &tab[(size_t)g * W];
+                const unsigned long long *e = &tab[((size_t)c * G + g) * W];
+                if (e[0] == ~0ull) continue;
+                d[0] = std::min(d[0], e[0]);
+                for (int i = 0; i < nagg; i++) {
+                    if (e[1 + 2 * i] == 0) continue;
+                    d[1 + 2 * i] += e[1 + 2 * i];
+                    if (agg_fns[i] == QE_AGG_SUM || agg_fns[i] == QE_AGG_AVG) {
+                        double a, b;
+                        std::memcpy(&a, &d[2 + 2 * i], 8);
+                        std::memcpy(&b, &e[2 + 2 * i], 8);
+                        a += b;
+                        std::memcpy(&d[2 + 2 * i], &a, 8);
+                    } else if (agg_fns[i] == QE_AGG_MIN) {
+                        d[2 + 2 * i] = (unsigned long long)std::min((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
+                    } else if (agg_fns[i] == QE_AGG_MAX) {
+                        d[2 + 2 * i] = (unsigned long long)std::max((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
+                    }
+                }
+            }
+        }
         // groups in insertion order = ascending first row (LinkedHashMap order, GroupByAggregationOperator.kt:22)
         std::vector<std::pair<unsigned long long, int64_t>> order;
         for (int64_t g = 0; g < G; g++)

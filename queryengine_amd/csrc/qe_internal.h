@@ -153,6 +153,8 @@ struct FusedGeometry {
     int ring_entries = 256;  // LDS entries per wave, buffer and output column: a chunk's kept rows stay in LDS
                              // until it is resolved; only an overflow spills to the global staging slot
     int lookback_k = 1;      // descriptor windows (of 64) loaded per look-back round
+    int gate_period_log2 = 0;   // output-write gate: period / window width in 10 ns ticks of s_memrealtime (0 = no gate)
+    int gate_width_log2 = 0;
     int stagger = 0;         // grade the sizes of the first chunks (needs subs_per_chunk % 16 == 0)
     int min_waves = 4;       // __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow
     int prio_mode = 1;       // 0 off, 1 rotate s_setprio among the waves of a SIMD per sub-tile, 2 per chunk
@@ -190,6 +192,7 @@ struct CodegenOutput {
     long long ngroups = 0;
     int table_words = 0;
     bool table_in_lds = false;
+    int table_copies = 1;        // global group table: copies merged on the host (one per XCD)
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);

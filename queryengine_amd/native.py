@@ -5,7 +5,9 @@ is missing, or no HIP device is present, the product path raises.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 import subprocess
 from typing import List, Optional, Sequence
 
@@ -108,6 +110,38 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  torch's libc10_hip.so asks for the unversioned name ``libamdhip64.so`` and finds the
+    copy bundled in torch/lib; that request never matches a ``libamdhip64.so.7`` from /opt/rocm that libqe_hip.so pulled
+    in earlier, so a process that creates a qe_ctx BEFORE importing torch (distributed.py needs torch) would end up with
+    two runtimes, and the second one sees no GPU ("No HIP GPUs are available").  The other order works because torch's
+    copy carries the SONAME libamdhip64.so.7 that libqe_hip.so asks for.  So: if torch is installed, load its bundled
+    runtime first (without importing torch) and let libqe_hip.so bind to it."""
+    if os.environ.get("QE_SYSTEM_HIP_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamd_comgr.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if not os.path.exists(path):
+            return
+    # the JIT compiler stays the image's own: hiprtc dlopens "libamd_comgr.so.3" by name and takes the first loaded
+    # library with that SONAME, so the ROCm one goes in before torch's (older) copy
+    system_comgr = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamd_comgr.so.3")
+    try:
+        if os.path.exists(system_comgr):
+            C.CDLL(system_comgr, mode=C.RTLD_LOCAL)    # local: no symbol interposition into torch's runtime
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            C.CDLL(os.path.join(libdir, name), mode=C.RTLD_GLOBAL)
+    except OSError:
+        return
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -115,6 +149,7 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(queryengine_amd has no CPU fallback)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
