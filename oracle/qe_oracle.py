@@ -340,3 +340,31 @@ def generate(spec: GenSpec, seed: int, row_begin: int, nrows: int, np_dtype) -> 
     lib().qo_generate(C.byref(spec), seed, row_begin, nrows, data.ctypes.data,
                       valid.ctypes.data if valid is not None else None)
     return data, (valid.astype(np.bool_) if valid is not None else None)
+
+
+# ---- strong columnar CPU baseline for config 2 (oracle/qe_columnar.c; bench.py cpu_baseline.columnar) ----------------
+_col_lib = None
+
+
+def columnar_config2(a: np.ndarray, b: np.ndarray, c: np.ndarray, a_limit: float = 100.0, c_limit: float = 0.5,
+                     nthreads: int = 0, out=None):
+    """SELECT a + b, c * 2.0 FROM t WHERE a < a_limit AND c < c_limit, hand-specialised, OpenMP.  Returns
+    (a+b values, c*2 values, threads used).  `out` = preallocated (int64[n+1], float64[n+1]) to keep allocation out of a timing."""
+    global _col_lib
+    if _col_lib is None:
+        path = os.path.join(_HERE, "libqe_columnar.so")
+        subprocess.run(["make", "-s", "-C", _HERE, "libqe_columnar.so"], check=True)
+        L = C.CDLL(path)
+        L.qc_config2.restype = C.c_int64
+        L.qc_config2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.POINTER(C.c_int32)]
+        _col_lib = L
+    n = len(a)
+    assert a.dtype == np.int64 and b.dtype == np.int64 and c.dtype == np.float64 and len(b) == n and len(c) == n
+    o0, o1 = out if out is not None else (np.empty(n + 1, dtype=np.int64), np.empty(n + 1, dtype=np.float64))
+    used = C.c_int32(0)
+    m = _col_lib.qc_config2(a.ctypes.data, b.ctypes.data, c.ctypes.data, n, a_limit, c_limit, o0.ctypes.data, o1.ctypes.data,
+                            nthreads, C.byref(used))
+    if m < 0:
+        raise MemoryError("qc_config2")
+    return o0[:m], o1[:m], int(used.value)

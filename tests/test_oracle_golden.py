@@ -143,3 +143,24 @@ def test_query_test_group_by_multiple_columns(oracle):
                                     [ColumnExpression("num", 2, D)], [oracle.SUM], mode)
         finished = [[bar, s, foo] for bar, foo, s in out]
         assert finished == [["A", 1.0, "a"], ["B", 5.0, "a"], ["B", 4.0, "b"], [None, None, "c"]]
+
+
+def test_columnar_cpu_baseline_matches_the_oracle(oracle):
+    """oracle/qe_columnar.c (bench.py's strong CPU baseline for config 2) is bit-identical to the row-at-a-time port."""
+    from queryengine_amd import workloads as W
+    from queryengine_amd.table import Column
+    n = 300_001
+    wl = W.config2(n)
+    cols = []
+    for c in wl.columns:
+        s = oracle.GenSpec()
+        s.kind, s.col_id, s.modulus, s.offset, s.step, s.aux_col_id, s.null_pct = \
+            c.kind, c.col_id, c.modulus, c.offset, c.step, c.aux_col_id, c.null_pct
+        data, valid = oracle.generate(s, 42, 0, n, np.float64 if c.type.name == "DOUBLE" else np.int64)
+        cols.append(Column(c.type, data, valid))
+    cols[2].data[[5, 77, 1000]] = [float("nan"), -0.0, float("inf")]
+    want = oracle.filter_project(cols, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+    for threads in (1, 3):
+        o0, o1, used = oracle.columnar_config2(cols[0].data, cols[1].data, cols[2].data, 100.0, 0.5, threads)
+        assert used == threads
+        assert np.array_equal(o0, want[0].data) and np.array_equal(o1.view(np.uint64), want[1].data.view(np.uint64))

@@ -7,9 +7,11 @@ from queryengine_amd.ast import ColumnExpression, Function, FunctionExpression, 
 from queryengine_amd.datatypes import DataType
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
-for nkeys in (10, 1000, 100000):
+KEYS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [10, 1000, 100000]
+TUNING = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else []
+for nkeys in KEYS:
     wl = W.config4(rows, nkeys=nkeys)
-    ctx = E.Context(device=0, profile=True)
+    ctx = E.Context(device=0, profile=True, tuning=TUNING)
     b = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], rows)
     s, v = ColumnExpression("s", 0, DataType.STRING), ColumnExpression("v", 1, DataType.DOUBLE)
     flt = FunctionExpression(Function.CMP_LT, [v, NumericLiteralExpression(0.5)], DataType.BOOLEAN)
