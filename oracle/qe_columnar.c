@@ -45,10 +45,13 @@ int64_t qc_config2(const int64_t *a, const int64_t *b, const double *c, int64_t 
         const int64_t lo = blk * QC_BLOCK, hi = lo + QC_BLOCK < n ? lo + QC_BLOCK : n;
         int64_t pos = counts[blk];
         for (int64_t i = lo; i < hi; i++) {
-            const int keep = ((double)a[i] < a_limit) & (c[i] < c_limit);
-            out0[pos] = (int64_t)((uint64_t)a[i] + (uint64_t)b[i]);   /* unconditional store, conditional advance */
-            out1[pos] = c[i] * 2.0;
-            pos += keep;
+            /* a store only for kept rows: an unconditional store + conditional advance would let the last dropped row of
+             * a block scribble over the first output of the next block, which another thread may already have written */
+            if (((double)a[i] < a_limit) & (c[i] < c_limit)) {
+                out0[pos] = (int64_t)((uint64_t)a[i] + (uint64_t)b[i]);
+                out1[pos] = c[i] * 2.0;
+                pos++;
+            }
         }
     }
     const int64_t total = counts[nblocks];
