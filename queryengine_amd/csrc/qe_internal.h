@@ -193,6 +193,12 @@ struct CodegenOutput {
     int table_words = 0;
     bool table_in_lds = false;
     int table_copies = 1;        // global group table: copies merged on the host (one per XCD)
+    // partitioned group-by (domains that do not fit LDS): rows are first scattered into nparts key-range partitions of
+    // part_groups (= 1 << part_shift) groups each, then every partition is aggregated in an LDS table
+    bool partitioned = false;
+    int part_shift = 0;
+    int part_groups = 0;
+    int nparts = 0;
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);

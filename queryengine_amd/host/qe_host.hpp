@@ -309,7 +309,7 @@ public:
     }
     int64_t resultCount() const { return count_; }
 
-private:
+protected:
     struct HostColumn {
         int type = 0;
         std::vector<uint8_t> data;
@@ -390,6 +390,79 @@ private:
     bool fetched_ = false;
 };
 
+enum class AggregationFunction { MIN = 0, MAX = 1, SUM = 2, COUNT = 3, AVG = 4 };   // ast/Functions.kt:24-26
+
+// Aggregation(Projection(Filter(Scan))) on the GPU: GlobalAggregationOperator.kt:7-36 when groupCount == 0 (one row,
+// even over an empty input), GroupByAggregationOperator.kt:7-76 otherwise (one row [keys..., accumulators...] per group
+// in insertion order).  The first `groupCount` input expressions are the keys.  COUNT finishes as the reference's Int
+// (Accumulators.kt:26-36): an int64 here.
+class GpuAggregationOperator : public GpuFilterProjectOperator {
+public:
+    GpuAggregationOperator(std::shared_ptr<Context> ctx, std::shared_ptr<ColumnarTable> table, std::vector<std::string> projection,
+                           ExpressionPtr filter, std::vector<ExpressionPtr> inputs, int groupCount,
+                           std::vector<AggregationFunction> functions)
+        : GpuFilterProjectOperator(std::move(ctx), std::move(table), std::move(projection), std::move(filter), std::move(inputs)),
+          groupCount_(groupCount) {
+        for (auto f : functions) fns_.push_back((int32_t)f);
+        if ((size_t)groupCount_ + fns_.size() != projs_.size()) throw std::invalid_argument("keys + aggregates != input expressions");
+    }
+    void open() override {
+        close();
+        if (!batch_) pin();
+        const int32_t nagg = (int32_t)fns_.size();
+        if (groupCount_ == 0) {
+            std::vector<double> vals((size_t)std::max(1, nagg));
+            std::vector<uint8_t> valid((size_t)std::max(1, nagg));
+            int64_t selected = 0;
+            ctx_->check(qe_filter_aggregate(ctx_->get(), batch_, filter_, projs_.data(), fns_.data(), nagg, vals.data(), valid.data(), &selected));
+            Row row;
+            for (int32_t i = 0; i < nagg; i++) row.push_back(finish(i, valid[i] != 0, vals[i]));
+            rows_.assign(1, row);
+        } else {
+            ctx_->check(qe_filter_groupby(ctx_->get(), batch_, filter_, projs_.data(), groupCount_, projs_.data() + groupCount_, fns_.data(),
+                                          nagg, &result_));
+            count_ = qe_result_count(result_);
+            fetch();
+            rows_.clear();
+            for (int64_t r = 0; r < count_; r++) {
+                Row row;
+                for (int k = 0; k < groupCount_; k++) row.push_back(out_[k].box(r));
+                for (int32_t i = 0; i < nagg; i++) {
+                    const Value v = out_[groupCount_ + i].box(r);
+                    row.push_back(finish(i, !isNull(v), isNull(v) ? 0.0 : std::get<double>(v)));
+                }
+                rows_.push_back(std::move(row));
+            }
+            qe_result_free(ctx_->get(), result_);
+            result_ = nullptr;
+            out_.clear();
+        }
+        opened_ = true;
+        idx_ = 0;
+    }
+    std::optional<Row> next() override {
+        if (!opened_) throw std::logic_error("Operator not opened");   // GroupByAggregationOperator.kt:57
+        if (idx_ >= (int64_t)rows_.size()) return std::nullopt;
+        return rows_[(size_t)idx_++];
+    }
+    void close() override {
+        GpuFilterProjectOperator::close();
+        rows_.clear();
+        opened_ = false;
+    }
+
+private:
+    Value finish(int32_t i, bool valid, double v) const {
+        if (fns_[i] == (int32_t)AggregationFunction::COUNT) return (int64_t)v;
+        if (!valid) return std::monostate{};
+        return v;
+    }
+    int groupCount_;
+    std::vector<int32_t> fns_;
+    std::vector<Row> rows_;
+    bool opened_ = false;
+};
+
 // ---- logical plan + physical dispatch (LogicalPlan.kt:7-12, Planner.kt:30-63) ----------------------------
 struct LogicalNode { virtual ~LogicalNode() = default; };
 struct LogicalScanNode : LogicalNode {
@@ -408,9 +481,24 @@ struct LogicalProjectionNode : LogicalNode {
     LogicalProjectionNode(std::shared_ptr<LogicalNode> s, std::vector<ExpressionPtr> e) : source(std::move(s)), expressions(std::move(e)) {}
 };
 
-// Projection(Filter(Scan)) / Projection(Scan) / Filter(Scan) / Scan -> ONE fused GPU operator.
-inline std::unique_ptr<Operator> buildPhysicalPlan(const TableRegistry &registry, const std::shared_ptr<LogicalNode> &plan,
+struct LogicalAggregationNode : LogicalNode {   // LogicalPlan.kt:11; the source is the projection of keys + aggregate inputs
+    std::shared_ptr<LogicalNode> source;
+    int groupCount;
+    std::vector<AggregationFunction> aggregateFunctions;
+    LogicalAggregationNode(std::shared_ptr<LogicalNode> s, int g, std::vector<AggregationFunction> f)
+        : source(std::move(s)), groupCount(g), aggregateFunctions(std::move(f)) {}
+};
+
+// Projection(Filter(Scan)) / Projection(Scan) / Filter(Scan) / Scan -> ONE fused GPU operator;
+// Aggregation(Projection(Filter(Scan))) -> ONE fused aggregate / group-by operator (Planner.kt:48-57).
+inline std::unique_ptr<Operator> buildPhysicalPlan(const TableRegistry &registry, const std::shared_ptr<LogicalNode> &planIn,
                                                    std::shared_ptr<Context> ctx) {
+    std::shared_ptr<LogicalNode> plan = planIn;
+    auto agg = std::dynamic_pointer_cast<LogicalAggregationNode>(plan);
+    if (agg) {
+        plan = agg->source;
+        if (!std::dynamic_pointer_cast<LogicalProjectionNode>(plan)) throw std::logic_error("aggregation needs its input projection");
+    }
     std::shared_ptr<LogicalNode> below = plan;
     std::vector<ExpressionPtr> projections;
     bool hasProjection = false;
@@ -433,6 +521,9 @@ inline std::unique_ptr<Operator> buildPhysicalPlan(const TableRegistry &registry
     if (!hasProjection)   // FilterOperator returns the scan row itself (FilterOperator.kt:21)
         for (size_t i = 0; i < scan->schema.fields.size(); i++)
             projections.push_back(col(scan->schema.fields[i].name, (int)i, scan->schema.fields[i].type));
+    if (agg)
+        return std::make_unique<GpuAggregationOperator>(std::move(ctx), table, names, filter, projections, agg->groupCount,
+                                                        agg->aggregateFunctions);
     return std::make_unique<GpuFilterProjectOperator>(std::move(ctx), table, names, filter, projections);
 }
 

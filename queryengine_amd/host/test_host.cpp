@@ -116,10 +116,68 @@ static void runAll(std::shared_ptr<Context> ctx, const char *modeName) {
     std::printf("mode %s: done\n", modeName);
 }
 
+// Aggregation on top of the path, fused mode.
+static void runAggregates(std::shared_ptr<Context> ctx) {
+    const Value N = std::monostate{};
+    auto D = DataType::DOUBLE, S = DataType::STRING;
+    // QueryTest.kt:15-30: SELECT bar, SUM(num), foo FROM table -> keys (bar, foo) in insertion order; the finish
+    // projection [bar, SUM, foo] is a re-ordering of [bar, foo, SUM]
+    {
+        Schema s{{{"foo", S}, {"bar", S}, {"num", D}}};
+        std::vector<Row> rows = {{std::string("a"), std::string("A"), 1.0}, {std::string("a"), std::string("B"), 2.0},
+                                 {std::string("a"), std::string("B"), 3.0}, {std::string("b"), std::string("B"), 4.0},
+                                 {std::string("b"), std::string("B"), N},   {std::string("c"), N, N}};
+        TableRegistry reg;
+        reg.registerTable("table", std::make_shared<ColumnarTable>(s, rows));
+        auto inputs = std::make_shared<LogicalProjectionNode>(std::make_shared<LogicalScanNode>("table", s),
+            std::vector<ExpressionPtr>{col("bar", 1, S), col("foo", 0, S), col("num", 2, D)});
+        auto plan = std::make_shared<LogicalAggregationNode>(inputs, 2, std::vector<AggregationFunction>{AggregationFunction::SUM});
+        auto op = buildPhysicalPlan(reg, plan, ctx);
+        std::vector<Row> want = {{std::string("A"), std::string("a"), 1.0}, {std::string("B"), std::string("a"), 5.0},
+                                 {std::string("B"), std::string("b"), 4.0}, {N, std::string("c"), N}};
+        for (int pass = 0; pass < 2; pass++) {
+            auto got = map<Row>(*op, [](const Row &r) { return r; });
+            EXPECT(got == want, "QueryTest group by (bar, foo) with SUM(num), insertion order");
+        }
+    }
+    // SimpleSumBenchmark.java:41-53: foo = bar = (double)(i / 1000), SUM(foo + 10 * bar): N = 1000 -> 0.0, N = 1e6 -> 5494500000.0
+    for (int64_t n : {(int64_t)1000, (int64_t)1000000}) {
+        Schema s{{{"foo", D}, {"bar", D}}};
+        std::vector<Row> rows;
+        rows.reserve((size_t)n);
+        for (int64_t i = 0; i < n; i++) rows.push_back({(double)(i / 1000), (double)(i / 1000)});
+        TableRegistry reg;
+        reg.registerTable("table", std::make_shared<ColumnarTable>(s, rows));
+        auto expr = fn(Function::ADD, {col("foo", 0, D), fn(Function::MUL, {num(10), col("bar", 1, D)})});
+        auto inputs = std::make_shared<LogicalProjectionNode>(std::make_shared<LogicalScanNode>("table", s), std::vector<ExpressionPtr>{expr, expr, expr});
+        auto plan = std::make_shared<LogicalAggregationNode>(inputs, 0, std::vector<AggregationFunction>{
+            AggregationFunction::SUM, AggregationFunction::COUNT, AggregationFunction::MAX});
+        auto op = buildPhysicalPlan(reg, plan, ctx);
+        auto got = map<Row>(*op, [](const Row &r) { return r; });
+        const double want = n == 1000 ? 0.0 : 5494500000.0;
+        EXPECT(got.size() == 1 && got[0].size() == 3 && got[0][0] == Value(want) && got[0][1] == Value((int64_t)n) &&
+               got[0][2] == Value((double)((n - 1) / 1000) * 11.0), "SimpleSumBenchmark SUM(foo + 10 * bar)");
+    }
+    // empty input: SUM => null, COUNT => 0 (Accumulators.kt:26-53)
+    {
+        Schema s{{{"x", D}}};
+        TableRegistry reg;
+        reg.registerTable("t", std::make_shared<ColumnarTable>(s, std::vector<Row>{{1.0}, {2.0}}));
+        auto flt = fn(Function::CMP_GT, {col("x", 0, D), num(5)});
+        auto inputs = std::make_shared<LogicalProjectionNode>(std::make_shared<LogicalFilterNode>(std::make_shared<LogicalScanNode>("t", s), flt),
+                                                              std::vector<ExpressionPtr>{col("x", 0, D), col("x", 0, D)});
+        auto plan = std::make_shared<LogicalAggregationNode>(inputs, 0, std::vector<AggregationFunction>{AggregationFunction::SUM, AggregationFunction::COUNT});
+        auto got = map<Row>(*buildPhysicalPlan(reg, plan, ctx), [](const Row &r) { return r; });
+        EXPECT(got.size() == 1 && isNull(got[0][0]) && got[0][1] == Value((int64_t)0), "empty aggregation: SUM null, COUNT 0");
+    }
+    std::printf("aggregates: done\n");
+}
+
 int main() {
     try {
         runAll(std::make_shared<Context>(0, Mode::GPU_FUSED), "GPU_FUSED");
         runAll(std::make_shared<Context>(0, Mode::GPU_PER_NODE), "GPU_PER_NODE");
+        runAggregates(std::make_shared<Context>(0, Mode::GPU_FUSED));
     } catch (const std::exception &e) {
         std::printf("FAIL exception: %s\n", e.what());
         return 2;
