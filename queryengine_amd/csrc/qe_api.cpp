@@ -983,7 +983,67 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         struct G1 { qe_ctx *c; void *p; ~G1() { c->pool.release(p); } } g1{ctx, d_tab};
         QE_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         const int64_t n = batch->nrows;
-        if (n > 0) {
+        const bool no_partition = (ctx->opts.tuning[5] & 256) != 0;   // debug bit 256: keep the global-atomic path (A/B measurements, tests)
+        if (n > 0 && cg.partitioned && !no_partition) {
+            // Domain too large for an LDS table: count -> scan -> scatter -> per-partition LDS aggregation
+            // (two streaming passes over the input and one over the records instead of one global atomic per value).
+            const int P = cg.nparts;
+            const int waves = plan->geo.threads / 64;
+            const int64_t chunk_rows = plan->geo.chunk_rows();
+            const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 8));
+            hipFunction_t f_count = nullptr, f_scatter = nullptr;
+            QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_gb_count"));
+            QE_HIP(hipModuleGetFunction(&f_scatter, plan->kernel.module, "qe_gb_scatter"));
+            std::vector<void *> temps;
+            struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
+            auto talloc = [&](size_t bytes) { void *q = ctx->pool.alloc(std::max<size_t>(bytes, 16)); temps.push_back(q); return q; };
+            uint32_t *d_counts = (uint32_t *)talloc((size_t)nchunks * P * 4);
+            unsigned long long *d_start = (unsigned long long *)talloc((size_t)(P + 1) * 8);
+            FusedParams p;
+            fill_inputs(p, batch, *plan);
+            p.nchunks = nchunks;
+            p.blk = (unsigned long long *)d_counts;
+            void *args[] = {&p};
+            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+            QE_HIP(hipModuleLaunchKernel(f_count, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+            launch_gb_scan(ctx->stream, d_counts, nchunks, P, d_start);
+            std::vector<unsigned long long> start((size_t)P + 1, 0);
+            QE_HIP(hipMemcpyAsync(start.data(), d_start, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            unsigned long long m_records = 0;
+            for (int j = 0; j < P; j++) {
+                const unsigned long long cnt = start[j];
+                start[j] = m_records;
+                m_records += cnt;
+            }
+            start[P] = m_records;
+            QE_HIP(hipMemcpyAsync(d_start, start.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (m_records > 0) {
+                p.l1 = d_start;
+                const int rec_words = 1 + cg.nvals;
+                p.desc = (unsigned long long *)talloc((size_t)m_records * 8 * rec_words);
+                GbAggArgs a{};
+                for (int i = 0; i < nagg; i++) {
+                    a.slot[i] = cg.val_slot[i];
+                    a.fn[i] = agg_fns[i];
+                }
+                QE_HIP(hipModuleLaunchKernel(f_scatter, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+                a.rec = p.desc;
+                a.rec_words = rec_words;
+                a.start = d_start;
+                a.table = d_tab;
+                a.ngroups = G;
+                a.nparts = P;
+                a.part_groups = cg.part_groups;
+                a.words = W;
+                a.nagg = nagg;
+                a.slices = std::max(1, std::min(64, 1024 / P));
+                launch_gb_aggregate(ctx->stream, a);
+            }
+            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));   // the temporaries go back to the pool when this scope ends
+        } else if (n > 0) {
             const int64_t sub_rows = plan->geo.sub_rows();
             const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
             const int waves = plan->geo.threads / 64;

@@ -199,6 +199,8 @@ struct CodegenOutput {
     int part_shift = 0;
     int part_groups = 0;
     int nparts = 0;
+    std::vector<int> val_slot;   // per aggregate: slot of its input value in a record (identical inputs share one)
+    int nvals = 0;               // distinct aggregate inputs; a record is 1 + nvals u64 words {header, values}
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);

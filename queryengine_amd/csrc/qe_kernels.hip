@@ -10,6 +10,7 @@ namespace qe {
 
 typedef unsigned long long u64;
 typedef long long i64;
+typedef unsigned int u32;
 
 __device__ __forceinline__ u64 mix64(u64 z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
@@ -171,6 +172,117 @@ void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
     hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
+}
+
+// ---- partitioned group-by -------------------------------------------------------------------------------------------
+// One workgroup per partition walks the chunks in order: exclusive scan of counts[chunk][part] along the chunk axis.
+__global__ void __launch_bounds__(256) gb_scan_kernel(u32 *counts, i64 nchunks, int nparts, u64 *totals) {
+    __shared__ u32 s_wave[4];
+    const int part = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 running = 0;
+    for (i64 c0 = 0; c0 < nchunks; c0 += 256) {
+        const i64 c = c0 + threadIdx.x;
+        const u32 v = c < nchunks ? counts[c * nparts + part] : 0u;
+        u32 incl = v;   // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        u32 before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before += s_wave[w];
+            total += s_wave[w];
+        }
+        if (c < nchunks) counts[c * nparts + part] = (u32)(running + before + incl - v);
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[part] = running;
+}
+
+void launch_gb_scan(hipStream_t s, uint32_t *counts, int64_t nchunks, int nparts, unsigned long long *totals) {
+    if (nparts <= 0) return;
+    hipLaunchKernelGGL(gb_scan_kernel, dim3((unsigned)nparts), dim3(256), 0, s, counts, (i64)nchunks, nparts, (u64 *)totals);
+}
+
+// order-preserving i64 image of a double (the same function as the JIT prelude's qe_ord_key)
+__device__ __forceinline__ i64 gb_ord_key(double d, bool for_min) {
+    i64 b = __builtin_bit_cast(i64, d);
+    if (d != d) b = for_min ? (i64)0xfff8000000000000ull : (i64)0x7ff8000000000000ull;
+    return b ^ ((b >> 63) & 0x7fffffffffffffffll);
+}
+
+__device__ __forceinline__ u64 gb_init_word(const GbAggArgs &a, int w) {
+    if (w == 0) return ~0ull;
+    if ((w & 1) == 0) {
+        const int fn = a.fn[(w - 2) >> 1];
+        if (fn == QE_AGG_MIN) return 0x7fffffffffffffffull;
+        if (fn == QE_AGG_MAX) return 0x8000000000000000ull;
+    }
+    return 0ull;
+}
+
+// grid = (slices, nparts): workgroup (s, p) aggregates slice s of partition p's records in an LDS table.
+__global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
+    extern __shared__ u64 s_tab[];
+    const int part = blockIdx.y;
+    const int W = a.words;
+    const int nent = a.part_groups * W;
+    for (int i = threadIdx.x; i < nent; i += 256) s_tab[i] = gb_init_word(a, i % W);
+    __syncthreads();
+    const u64 lo = a.start[part], hi = a.start[part + 1];
+    const u64 len = hi - lo;
+    const u64 per = (len + a.slices - 1) / a.slices;
+    const u64 b = lo + per * blockIdx.x;
+    const u64 e = b + per < hi ? b + per : hi;
+    const int RW = a.rec_words;
+    for (u64 i = b + threadIdx.x; i < e; i += 256) {
+        const u64 *rec = a.rec + i * (u64)RW;
+        u64 h, v0 = 0;
+        if (RW == 2) { const u64x2 t = *(const u64x2 *)rec; h = t.x; v0 = t.y; }
+        else h = rec[0];
+        u64 *ent = s_tab + (i64)((h >> 8) & 0xffffull) * W;
+        atomicMin(ent, h >> 24);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < a.nagg && ((h >> k) & 1ull)) {
+                atomicAdd(ent + 1 + 2 * k, 1ull);
+                const double v = __builtin_bit_cast(double, RW == 2 ? v0 : rec[1 + a.slot[k]]);
+                const int fn = a.fn[k];
+                if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(ent + 2 + 2 * k), v);
+                else if (fn == QE_AGG_MIN) atomicMin((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, true));
+                else if (fn == QE_AGG_MAX) atomicMax((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, false));
+            }
+        }
+    }
+    __syncthreads();
+    // merge into the global table (several slices may share a partition)
+    for (int g = threadIdx.x; g < a.part_groups; g += 256) {
+        const i64 gg = (i64)part * a.part_groups + g;
+        const u64 *ent = s_tab + (i64)g * W;
+        if (gg >= a.ngroups || ent[0] == ~0ull) continue;
+        u64 *d = a.table + gg * W;
+        atomicMin(d, ent[0]);
+        for (int k = 0; k < a.nagg; ++k) {
+            if (ent[1 + 2 * k] == 0) continue;
+            atomicAdd(d + 1 + 2 * k, ent[1 + 2 * k]);
+            const int fn = a.fn[k];
+            if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(d + 2 + 2 * k), __builtin_bit_cast(double, ent[2 + 2 * k]));
+            else if (fn == QE_AGG_MIN) atomicMin((i64 *)(d + 2 + 2 * k), (i64)ent[2 + 2 * k]);
+            else if (fn == QE_AGG_MAX) atomicMax((i64 *)(d + 2 + 2 * k), (i64)ent[2 + 2 * k]);
+        }
+    }
+}
+
+void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a) {
+    if (a.nparts <= 0) return;
+    const size_t lds = (size_t)a.part_groups * a.words * 8;
+    hipLaunchKernelGGL(gb_aggregate_kernel, dim3((unsigned)a.slices, (unsigned)a.nparts), dim3(256), lds, s, a);
 }
 
 }  // namespace qe

@@ -174,3 +174,48 @@ def test_group_by_matches_oracle(gpu_ctx, oracle):
                 else:
                     assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
     batch.free()
+
+
+@pytest.mark.parametrize("case", ["partitioned", "partitioned_wide_domain", "global_atomics"])
+def test_group_by_large_domain_matches_oracle(case, oracle):
+    """Domains whose accumulator table does not fit LDS: the partitioned path (count -> scan -> scatter -> per-partition
+    LDS aggregation) and, with debug bit 256, the global-atomic path.  Ragged last chunk, null keys, null values, a
+    filter; groups must come out in the reference's insertion order (GroupByAggregationOperator.kt:22)."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(11)
+    wide = case == "partitioned_wide_domain"
+    n = 400_003 if wide else 300_017
+    nkeys = 300_000 if wide else 3000
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 256, 0, 0] if case == "global_atomics" else [])
+    d = ["k%06d" % i for i in range(nkeys)]
+    s = Column(S, rng.integers(0, nkeys, n).astype(np.int32), rng.random(n) > 0.05, d)
+    p = Column(B, rng.random(n) > 0.5, rng.random(n) > 0.1)
+    x = Column(D, np.round(rng.normal(0, 100, n)), rng.random(n) > 0.2)
+    y = Column(I64, rng.integers(-1000, 1000, n))
+    Sx, P, X, Y = ColumnExpression("s", 0, S), ColumnExpression("p", 1, B), ColumnExpression("x", 2, D), ColumnExpression("y", 3, I64)
+    keys = [Sx, P]
+    if wide:
+        exprs, aggs = [X], [oracle.SUM]
+    else:
+        exprs = [X, X, X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)]
+        aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
+    flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
+    batch = E.DeviceBatch.from_columns(ctx, [s, p, x, y])
+    for f in (None, flt):
+        res = E.filter_groupby(ctx, batch, ctx.compile(f) if f is not None else None,
+                               [ctx.compile(k) for k in keys], [ctx.compile(e) for e in exprs], aggs)
+        cols = res.to_columns()
+        got = [[c.value(i) for c in cols] for i in range(res.count)]
+        res.free()
+        want = oracle.filter_groupby([s, p, x, y], f, keys, exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert len(got) == len(want) and len(got) > 5000
+        for g, w in zip(got, want):
+            assert g[:2] == w[:2]
+            for a, b, fn in zip(g[2:], w[2:], aggs):
+                if b is None or fn != oracle.AVG:
+                    assert a == b, (g, w)
+                else:
+                    assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+    batch.free()
+    ctx.close()
