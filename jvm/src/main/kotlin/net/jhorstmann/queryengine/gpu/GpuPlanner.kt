@@ -1,6 +1,7 @@
 // The seam: a GPU branch for buildPhysicalPlan (evaluator/Planner.kt:30-63).  The reference's
 // Mode enum (evaluator/Compiler.kt:5-7) gains GPU; Projection(Filter(Scan)), Projection(Scan) and
-// Filter(Scan) over a ColumnarSource collapse into ONE GpuFilterProjectOperator; every other plan
+// Filter(Scan) over a ColumnarSource collapse into ONE GpuFilterProjectOperator, Aggregation over them into ONE
+// GpuAggregationOperator; every other plan
 // shape falls through to the unmodified reference code.
 package net.jhorstmann.queryengine.gpu
 
@@ -15,6 +16,14 @@ fun buildGpuPhysicalPlan(ctx: MemorySegment, registry: TableRegistry, plan: Logi
         is LogicalScanNode -> n to null
         is LogicalFilterNode -> (n.source as? LogicalScanNode)?.let { it to n.filter }
         else -> null
+    }
+    // Aggregation(Projection(Filter(Scan))) -> one fused aggregate / group-by operator (Planner.kt:48-57)
+    if (plan is LogicalAggregationNode) {
+        val inner = plan.source as? LogicalProjectionNode
+        val m = inner?.let { scanOf(it.source) }
+        val table = m?.let { registry.getTable(it.first.table) }
+        if (inner != null && m != null && table is ColumnarSource)
+            return GpuAggregationOperator(ctx, table, m.second, inner.expressions, plan.groupCount, plan.aggregateFunctions)
     }
     val (projections, below) = when (plan) {
         is LogicalProjectionNode -> plan.expressions to plan.source

@@ -31,6 +31,9 @@ internal object QeNative {
     val qe_filter_project_prepare = handle("qe_filter_project_prepare", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT)
     val qe_filter_aggregate = handle("qe_filter_aggregate", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT,
             ADDRESS, ADDRESS, ADDRESS)
+    // ctx, batch, filter|NULL, qe_expr*[nkeys], nkeys, qe_expr*[nagg], int32 fns[nagg], nagg, qe_result** -> status
+    val qe_filter_groupby = handle("qe_filter_groupby", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS,
+            JAVA_INT, ADDRESS)
     val qe_result_count = handle("qe_result_count", JAVA_LONG, ADDRESS)
     val qe_result_ncols = handle("qe_result_ncols", JAVA_INT, ADDRESS)
     val qe_result_column = handle("qe_result_column", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS)
