@@ -236,7 +236,10 @@ def main():
                        "sharding": "contiguous row ranges by global row index, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "qe_fused", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": ("qe_fp_count + gb_scan + qe_fp_write (two-pass form, chosen at selectivity >= 0.6)"
+                                    if args.exec_mode == "fused" and wl.filter is not None and nout >= 0.6 * nrows else
+                                    "qe_fused" if args.exec_mode == "fused" else "per-node kernels"),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_stream_read_gbps": stream_gbps},
         }
         if gather_info is not None:

@@ -720,95 +720,131 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             p.outvalid[i] = oc.bytes_valid;
         }
     }
-    const int64_t chunk_rows = plan->geo.chunk_rows();
-    const int waves = plan->geo.threads / 64;
-    const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan);
-    // the first `stagger_chunks` chunks (one per resident wave) have graded sizes ((7c mod 16)+1)/16
-    int64_t stagger_chunks = plan->geo.stagger ? max_grid * waves : 0, stagger_rows = 0, nchunks = 0;
-    {
-        const int64_t sixteenth = chunk_rows / 16;
-        int64_t c = 0, rows = 0;
-        // whole periods of 16 chunks cover 136 sixteenths
-        const int64_t periods = std::min<int64_t>(stagger_chunks / 16, n / (136 * sixteenth));
-        c = periods * 16;
-        rows = periods * 136 * sixteenth;
-        while (c < stagger_chunks && rows < n) {
-            rows += (((7 * c) & 15) + 1) * sixteenth;
-            c++;
-        }
-        if (rows >= n) {
-            nchunks = c;
-            stagger_chunks = c;        // every chunk is a staggered one
-            stagger_rows = rows;
-        } else {
-            stagger_rows = rows;
-            nchunks = stagger_chunks + (n - rows + chunk_rows - 1) / chunk_rows;
-        }
-    }
-    if (nchunks >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit chunk tickets");
-    const int grid = (int)std::min<int64_t>((nchunks + waves - 1) / waves, max_grid);
-    // scratch: look-back descriptors + one staging slot (chunk_rows rows per output column) per resident wave
-    std::vector<void *> scratch;
-    struct ScratchGuard {
-        qe_ctx *c; std::vector<void *> &v;
-        ~ScratchGuard() { for (void *q : v) c->pool.release(q); }
-    } sg{ctx, scratch};
-    // descriptors: [nchunks] level 0, then [nblocks] level 1, then [nblocks] block counters -- one allocation,
-    // zeroed by ONE memset on the stream before every launch
-    const int64_t nblocks = (nchunks + 63) / 64;
-    const size_t desc_words = (size_t)nchunks + 2 * (size_t)nblocks;
-    unsigned long long *desc = (unsigned long long *)ctx->pool.alloc(desc_words * 8);
-    scratch.push_back(desc);
-    if (plan->cg.has_filter) {
-        const size_t slots = (size_t)grid * waves * plan->geo.nbuf;   // one staging (overflow) slot per LDS buffer
-        for (size_t i = 0; i < res->cols.size(); i++) {
-            const OutColumn &oc = res->cols[i];
-            const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);
-            p.stage[i] = ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows() * w);
-            scratch.push_back(p.stage[i]);
-            if (oc.nullable) {
-                p.stagevalid[i] = (unsigned char *)ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows());
-                scratch.push_back(p.stagevalid[i]);
+    // Two-pass form for HIGH selectivity (chosen from the selectivity this plan showed last time): count the kept rows
+    // per chunk, scan, then stream again and store every kept row straight at its final position -- no look-back, no
+    // LDS ring, no staging round trip (which costs 48 B per kept row instead of 16 once the ring overflows).
+    const bool force_two_pass = (ctx->opts.tuning[5] & 512) != 0, never_two_pass = (ctx->opts.tuning[5] & 1024) != 0;
+    const bool two_pass = plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
+                          (force_two_pass || plan->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6
+    unsigned long long total = 0;
+    if (two_pass) {
+        const int64_t chunk_rows = plan->geo.chunk_rows();
+        const int waves = plan->geo.threads / 64;
+        const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 8));
+        hipFunction_t f_count = nullptr, f_write = nullptr;
+        QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_fp_count"));
+        QE_HIP(hipModuleGetFunction(&f_write, plan->kernel.module, "qe_fp_write"));
+        uint32_t *d_counts = (uint32_t *)ctx->pool.alloc((size_t)nchunks * 4);
+        struct CG { qe_ctx *c; void *q; ~CG() { c->pool.release(q); } } cg_guard{ctx, d_counts};
+        p.capacity = cap;
+        p.nchunks = nchunks;
+        p.blk = (unsigned long long *)d_counts;
+        p.error = ctx->d_ctrl + 1;
+        p.total = (unsigned long long *)(ctx->d_ctrl + 2);
+        void *args[] = {&p};
+        QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        QE_HIP(hipModuleLaunchKernel(f_count, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+        launch_gb_scan(ctx->stream, d_counts, nchunks, 1, p.total);   // counts -> exclusive offsets, *total = kept rows
+        QE_HIP(hipModuleLaunchKernel(f_write, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        collect_time(ctx);
+        total = ctx->h_ctrl[1];
+    } else {
+        const int64_t chunk_rows = plan->geo.chunk_rows();
+        const int waves = plan->geo.threads / 64;
+        const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan);
+        // the first `stagger_chunks` chunks (one per resident wave) have graded sizes ((7c mod 16)+1)/16
+        int64_t stagger_chunks = plan->geo.stagger ? max_grid * waves : 0, stagger_rows = 0, nchunks = 0;
+        {
+            const int64_t sixteenth = chunk_rows / 16;
+            int64_t c = 0, rows = 0;
+            // whole periods of 16 chunks cover 136 sixteenths
+            const int64_t periods = std::min<int64_t>(stagger_chunks / 16, n / (136 * sixteenth));
+            c = periods * 16;
+            rows = periods * 136 * sixteenth;
+            while (c < stagger_chunks && rows < n) {
+                rows += (((7 * c) & 15) + 1) * sixteenth;
+                c++;
+            }
+            if (rows >= n) {
+                nchunks = c;
+                stagger_chunks = c;        // every chunk is a staggered one
+                stagger_rows = rows;
+            } else {
+                stagger_rows = rows;
+                nchunks = stagger_chunks + (n - rows + chunk_rows - 1) / chunk_rows;
             }
         }
-    }
-    p.capacity = cap;
-    p.desc = desc;
-    p.l1 = desc + nchunks;
-    p.blk = desc + nchunks + nblocks;
-    p.ticket = ctx->d_ctrl;
-    p.error = ctx->d_ctrl + 1;
-    p.total = (unsigned long long *)(ctx->d_ctrl + 2);
-    p.nchunks = nchunks;
-    p.stagger_chunks = stagger_chunks;
-    p.stagger_rows = stagger_rows;
-    p.stats = (unsigned long long *)(ctx->d_ctrl + 16);   // bytes 64..95 of the control block
-    if (ctx->opts.tuning[5] & 32) {
-        p.trace = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 32);
-        scratch.push_back(p.trace);
-        QE_HIP(hipMemsetAsync(p.trace, 0, (size_t)nchunks * 32, ctx->stream));
-    }
-    // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
-    QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
-    QE_HIP(hipMemsetAsync(desc, 0, desc_words * 8, ctx->stream));
-    launch_fused(ctx, *plan, p, grid);
-    QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
-    QE_HIP(hipStreamSynchronize(ctx->stream));
-    collect_time(ctx);
-    if ((ctx->opts.tuning[5] & 32) && std::getenv("QE_TRACE_FILE")) {
-        std::vector<unsigned long long> tr((size_t)nchunks * 4);
-        QE_HIP(hipMemcpy(tr.data(), p.trace, tr.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE *f = std::fopen(std::getenv("QE_TRACE_FILE"), "wb")) {
-            std::fwrite(tr.data(), 8, tr.size(), f);
-            std::fclose(f);
+        if (nchunks >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit chunk tickets");
+        const int grid = (int)std::min<int64_t>((nchunks + waves - 1) / waves, max_grid);
+        // scratch: look-back descriptors + one staging slot (chunk_rows rows per output column) per resident wave
+        std::vector<void *> scratch;
+        struct ScratchGuard {
+            qe_ctx *c; std::vector<void *> &v;
+            ~ScratchGuard() { for (void *q : v) c->pool.release(q); }
+        } sg{ctx, scratch};
+        // descriptors: [nchunks] level 0, then [nblocks] level 1, then [nblocks] block counters -- one allocation,
+        // zeroed by ONE memset on the stream before every launch
+        const int64_t nblocks = (nchunks + 63) / 64;
+        const size_t desc_words = (size_t)nchunks + 2 * (size_t)nblocks;
+        unsigned long long *desc = (unsigned long long *)ctx->pool.alloc(desc_words * 8);
+        scratch.push_back(desc);
+        if (plan->cg.has_filter) {
+            const size_t slots = (size_t)grid * waves * plan->geo.nbuf;   // one staging (overflow) slot per LDS buffer
+            for (size_t i = 0; i < res->cols.size(); i++) {
+                const OutColumn &oc = res->cols[i];
+                const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);
+                p.stage[i] = ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows() * w);
+                scratch.push_back(p.stage[i]);
+                if (oc.nullable) {
+                    p.stagevalid[i] = (unsigned char *)ctx->pool.alloc(slots * (size_t)plan->geo.slot_rows());
+                    scratch.push_back(p.stagevalid[i]);
+                }
+            }
         }
+        p.capacity = cap;
+        p.desc = desc;
+        p.l1 = desc + nchunks;
+        p.blk = desc + nchunks + nblocks;
+        p.ticket = ctx->d_ctrl;
+        p.error = ctx->d_ctrl + 1;
+        p.total = (unsigned long long *)(ctx->d_ctrl + 2);
+        p.nchunks = nchunks;
+        p.stagger_chunks = stagger_chunks;
+        p.stagger_rows = stagger_rows;
+        p.stats = (unsigned long long *)(ctx->d_ctrl + 16);   // bytes 64..95 of the control block
+        if (ctx->opts.tuning[5] & 32) {
+            p.trace = (unsigned long long *)ctx->pool.alloc((size_t)nchunks * 32);
+            scratch.push_back(p.trace);
+            QE_HIP(hipMemsetAsync(p.trace, 0, (size_t)nchunks * 32, ctx->stream));
+        }
+        // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
+        QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+        QE_HIP(hipMemsetAsync(desc, 0, desc_words * 8, ctx->stream));
+        launch_fused(ctx, *plan, p, grid);
+        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        collect_time(ctx);
+        if ((ctx->opts.tuning[5] & 32) && std::getenv("QE_TRACE_FILE")) {
+            std::vector<unsigned long long> tr((size_t)nchunks * 4);
+            QE_HIP(hipMemcpy(tr.data(), p.trace, tr.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(std::getenv("QE_TRACE_FILE"), "wb")) {
+                std::fwrite(tr.data(), 8, tr.size(), f);
+                std::fclose(f);
+            }
+        }
+        if (ctx->opts.tuning[5] & 16)
+            std::fprintf(stderr, "[qe stats] chunks %llu failed_tries %llu forced_waits %llu blocking_spins %llu\n", ctx->h_ctrl[11],
+                         ctx->h_ctrl[8], ctx->h_ctrl[10], ctx->h_ctrl[9]);
+        const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+        if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
+        total = ctx->h_ctrl[1];
     }
-    if (ctx->opts.tuning[5] & 16)
-        std::fprintf(stderr, "[qe stats] chunks %llu failed_tries %llu forced_waits %llu blocking_spins %llu\n", ctx->h_ctrl[11],
-                     ctx->h_ctrl[8], ctx->h_ctrl[10], ctx->h_ctrl[9]);
-    const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
-    if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
-    const unsigned long long total = ctx->h_ctrl[1];
+    plan->last_selectivity = (double)total / (double)n;
     if ((int64_t)total > cap)
         fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(total) + " rows but result_capacity_rows is " +
                                      std::to_string(cap));

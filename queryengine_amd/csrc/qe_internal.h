@@ -185,6 +185,7 @@ struct CodegenOutput {
     std::vector<OutSpec> outs;
     std::vector<int> used_cols;  // batch column index per kernel column slot
     bool has_filter = false;
+    bool two_pass = false;       // the module also holds qe_fp_count / qe_fp_write (count + direct ordered write)
     // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
     // accumulator table geometry: ngroups rows of table_words u64 words {first row, (count, acc) per aggregate}
     std::vector<OutSpec> keys;
@@ -231,6 +232,7 @@ struct Plan {
     Kernel kernel;
     FusedGeometry geo;
     bool aggregate = false;
+    mutable double last_selectivity = -1.0;   // kept / scanned rows of the last execution (picks the two-pass form)
 };
 
 // kernel parameter block of the generated fused kernel (must match the prelude in qe_codegen.cpp)

@@ -46,8 +46,18 @@ def gpu_ctx_per_node(native_lib):
     ctx.close()
 
 
-@pytest.fixture(params=["fused", "per_node"])
-def any_ctx(request, gpu_ctx, gpu_ctx_per_node):
-    """Every parity test runs through BOTH execution modes, like the reference's
+@pytest.fixture(scope="session")
+def gpu_ctx_two_pass(native_lib):
+    """Fused executor forced into its two-pass form (count, scan, direct ordered write) -- normally chosen only after a
+    plan has shown high selectivity (debug bit 512 of qe_options.tuning[5])."""
+    from queryengine_amd import engine
+    ctx = engine.Context(device=0, tuning=[0, 0, 0, 0, 0, 512, 0, 0])
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(params=["fused", "per_node", "fused_two_pass"])
+def any_ctx(request, gpu_ctx, gpu_ctx_per_node, gpu_ctx_two_pass):
+    """Every parity test runs through ALL execution forms, like the reference's
     @EnumSource(Mode::class) tests run through all three evaluators (CompilerTest.kt:13)."""
-    return gpu_ctx if request.param == "fused" else gpu_ctx_per_node
+    return {"fused": gpu_ctx, "per_node": gpu_ctx_per_node, "fused_two_pass": gpu_ctx_two_pass}[request.param]

@@ -303,3 +303,26 @@ def test_full_size_1b_rows_properties(gpu_ctx, oracle):
     assert r2.count == r1.count and np.array_equal(r2.column_to_host(0).data, rid)
     r1.free(); r2.free(); batch.free()
     gpu_ctx.trim()
+
+
+def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
+    """The fused executor remembers the selectivity a plan showed: the first execution is single-pass, the next one of a
+    high-selectivity plan runs count -> scan -> direct write.  Both give the reference's rows in input order."""
+    from queryengine_amd import engine as E
+    from queryengine_amd import workloads as W
+    n = 150_001
+    ctx = E.Context(device=0)
+    for a_limit, c_limit in ((1000, 1.0), (1000, 0.5), (100, 0.5)):
+        wl = W.config2(n, a_limit=a_limit, c_limit=c_limit, null_pct=1)
+        batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
+        host = [batch.column_to_host(j) for j in range(batch.ncols)]
+        want = oracle.filter_project(host, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+        cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
+        for rep in range(3):
+            res = E.filter_project(ctx, batch, cf, cp)
+            got = res.to_columns()
+            res.free()
+            for g, w in zip(got, want):
+                assert_columns_equal(g, w, f"a<{a_limit} c<{c_limit} rep {rep}")
+        batch.free()
+    ctx.close()
