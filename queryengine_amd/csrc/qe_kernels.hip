@@ -168,10 +168,38 @@ void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, un
                        (i64)(dst_bytes / 8 / waves), write_every, window_period, window_len, blocks_per_event < 1 ? 1 : blocks_per_event, store_kind);
 }
 
+// Calibration of SPARSE streaming reads (late materialisation): the same loop, but a lane loads its 16 bytes only when a
+// hash of the vector index falls below `pct` -- what fraction of the dense time does a `pct` % selection cost?
+__global__ void __launch_bounds__(256) stream_read_sparse_kernel(const u64x2 *src, i64 nvec, u64 *sink, unsigned pct) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 acc = 0;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+        u64x2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u64 idx = (u64)(i + j * stride);
+            u64 h = idx * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 32;
+            v[j].x = 0; v[j].y = 0;
+            if ((unsigned)(h % 100u) < pct) v[j] = __builtin_nontemporal_load(src + idx);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y;
+    }
+    if (acc == 0x0123456789abcdefull) sink[0] = acc;
+}
+
 void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink) {
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
-    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
+    static const int sparse_pct = std::getenv("QE_CALIB_SPARSE_PCT") ? std::atoi(std::getenv("QE_CALIB_SPARSE_PCT")) : -1;
+    if (sparse_pct >= 0)
+        hipLaunchKernelGGL(stream_read_sparse_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink, (unsigned)sparse_pct);
+    else
+        hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
 }
 
 // ---- partitioned group-by -------------------------------------------------------------------------------------------
