@@ -236,6 +236,7 @@ def main():
                        "sharding": "contiguous row ranges by global row index, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_gbps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
                          "kernel": ("qe_fp_count + gb_scan + qe_fp_write (two-pass form, chosen at selectivity >= 0.6)"
                                     if args.exec_mode == "fused" and wl.filter is not None and nout >= 0.6 * nrows else
                                     "qe_fused" if args.exec_mode == "fused" else "per-node kernels"),
