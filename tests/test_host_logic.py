@@ -252,3 +252,19 @@ def test_rewrite_aggregates_reference_fixtures():
     assert rewriteAggregates(LogicalProjectionNode(scan2, (CE("foo", 0, D),))) is None
     with pytest.raises(InvalidAggregatesException):
         rewriteAggregates(LogicalProjectionNode(scan2, (AFE(AF.SUM, [AFE(AF.SUM, [CE("foo", 0, D)], D)], D),)))
+
+
+def test_late_materialisation_splits_the_filter_into_conjunct_stages(native_lib, tmp_path):
+    """Generated source (planning-only context, no GPU): the filter's AND chain becomes qe_conj0 / qe_conj1, the
+    projection-only column is loaded under the live-row guard; tuning[5] bit 2048 restores the load-everything form."""
+    from queryengine_amd import workloads as W
+    from queryengine_amd.prepared import _schema_columns
+    wl = W.config2(1000)
+    for tuning, staged in (([], True), ([0, 0, 0, 0, 0, 2048, 0, 0], False)):
+        ctx = E.Context(device=None, jit_cache_dir=str(tmp_path / ("s" if staged else "u")), tuning=tuning)
+        batch = E.DeviceBatch.describe(ctx, _schema_columns(wl))
+        src = E.generated_source(ctx, batch, ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections])
+        assert ("qe_conj0(" in src and "qe_conj1(" in src) == staged
+        assert ("if (keep[u][0] || keep[u][1]) {" in src) == staged
+        assert "qe_fp_count" in src and "qe_fp_write" in src       # the two-pass form lives in the same module
+        ctx.close()
