@@ -326,3 +326,24 @@ def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
                 assert_columns_equal(g, w, f"a<{a_limit} c<{c_limit} rep {rep}")
         batch.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_conjunctive_filters(any_ctx, oracle, seed):
+    """Filters that ARE top-level AND chains of 2-4 random boolean trees over null-heavy columns, several chunks of rows:
+    the staged (late-materialisation) evaluation -- a conjunct is only evaluated, and its columns only loaded, for rows
+    on which every earlier conjunct was a non-null TRUE -- must keep exactly the rows the reference's Kleene AND keeps."""
+    rnd = random.Random(1000 + seed)
+    rng = np.random.default_rng(1000 + seed)
+    n = 40_000 + seed * 1111
+    schema = [("a", D), ("b", D), ("i", I64), ("j", I32), ("p", B), ("q", B), ("s", S)]
+    dictionary = ["k%04d" % i for i in range(8)]
+    cols = [random_column(rng, t, n, null_frac=rnd.choice([0.0, 0.1, 0.5]), dictionary=dictionary) for _, t in schema]
+    g = ExprGen(rnd, schema)
+    g.dicts = {"s": dictionary}
+    for _ in range(2):
+        flt = g.boolean(2)
+        for _ in range(rnd.randint(1, 3)):
+            flt = fn(Fn.AND, flt, g.boolean(2), t=B) if rnd.random() < 0.5 else fn(Fn.AND, g.boolean(2), flt, t=B)
+        projs = [g.numeric(2) if rnd.random() < 0.7 else g.boolean(2) for _ in range(rnd.randint(1, 3))]
+        run_both(any_ctx, oracle, cols, flt, projs)
