@@ -1063,6 +1063,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 GbAggArgs a{};
                 for (int i = 0; i < nagg; i++) {
                     a.slot[i] = cg.val_slot[i];
+                    a.cnt_src[i] = cg.cnt_src[i];
                     a.fn[i] = agg_fns[i];
                 }
                 QE_HIP(hipModuleLaunchKernel(f_scatter, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
@@ -1101,8 +1102,8 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 if (e[0] == ~0ull) continue;
                 d[0] = std::min(d[0], e[0]);
                 for (int i = 0; i < nagg; i++) {
-                    if (e[1 + 2 * i] == 0) continue;
-                    d[1 + 2 * i] += e[1 + 2 * i];
+                    if (e[1 + 2 * cg.cnt_src[i]] == 0) continue;
+                    if (cg.cnt_src[i] == i) d[1 + 2 * i] += e[1 + 2 * i];
                     if (agg_fns[i] == QE_AGG_SUM || agg_fns[i] == QE_AGG_AVG) {
                         double a, b;
                         std::memcpy(&a, &d[2 + 2 * i], 8);
@@ -1175,7 +1176,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             bool any_null = false;
             for (int64_t j = 0; j < m; j++) {
                 const unsigned long long *e = &tab[(size_t)order[j].second * W];
-                const unsigned long long cnt = e[1 + 2 * i];
+                const unsigned long long cnt = e[1 + 2 * cg.cnt_src[i]];
                 const unsigned long long raw = e[2 + 2 * i];
                 double v = 0.0;
                 bool ok = true;

@@ -195,6 +195,8 @@ struct CodegenOutput {
     int table_words = 0;
     bool table_in_lds = false;
     int table_copies = 1;        // global group table: copies merged on the host (one per XCD)
+    std::vector<int> cnt_src;    // per aggregate: the aggregate whose count word holds its count (non-nullable inputs all
+                                 // see every kept row of the group: they share the first one's counter, one atomic less each)
     // partitioned group-by (domains that do not fit LDS): rows are first scattered into nparts key-range partitions of
     // part_groups (= 1 << part_shift) groups each, then every partition is aggregated in an LDS table
     bool partitioned = false;

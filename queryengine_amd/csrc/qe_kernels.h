@@ -27,6 +27,7 @@ struct GbAggArgs {
     const unsigned long long *rec;       // records of rec_words u64: {row:40 | local group:16 | non-null bits:8}, values (f64 bits)
     int rec_words;
     int slot[8];                         // per aggregate: which value of the record it consumes
+    int cnt_src[8];                      // per aggregate: the aggregate whose count word it shares (itself if nullable)
     const unsigned long long *start;     // first record of every partition (nparts + 1 entries)
     unsigned long long *table;
     long long ngroups;

@@ -275,11 +275,11 @@ __global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
         if (RW == 2) { const u64x2 t = *(const u64x2 *)rec; h = t.x; v0 = t.y; }
         else h = rec[0];
         u64 *ent = s_tab + (i64)((h >> 8) & 0xffffull) * W;
-        atomicMin(ent, h >> 24);
+        if ((h >> 24) < *(volatile u64 *)ent) atomicMin(ent, h >> 24);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k < a.nagg && ((h >> k) & 1ull)) {
-                atomicAdd(ent + 1 + 2 * k, 1ull);
+                if (a.cnt_src[k] == k) atomicAdd(ent + 1 + 2 * k, 1ull);
                 const double v = __builtin_bit_cast(double, RW == 2 ? v0 : rec[1 + a.slot[k]]);
                 const int fn = a.fn[k];
                 if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(ent + 2 + 2 * k), v);
@@ -297,8 +297,8 @@ __global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
         u64 *d = a.table + gg * W;
         atomicMin(d, ent[0]);
         for (int k = 0; k < a.nagg; ++k) {
-            if (ent[1 + 2 * k] == 0) continue;
-            atomicAdd(d + 1 + 2 * k, ent[1 + 2 * k]);
+            if (ent[1 + 2 * a.cnt_src[k]] == 0) continue;
+            if (a.cnt_src[k] == k) atomicAdd(d + 1 + 2 * k, ent[1 + 2 * k]);
             const int fn = a.fn[k];
             if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(d + 2 + 2 * k), __builtin_bit_cast(double, ent[2 + 2 * k]));
             else if (fn == QE_AGG_MIN) atomicMin((i64 *)(d + 2 + 2 * k), (i64)ent[2 + 2 * k]);
