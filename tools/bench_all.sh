@@ -21,3 +21,4 @@ for line in open("gpurun_out/bench_all.jsonl"):
     print(f'{j["config"]["workload"][:70]:70s} {j["config"]["exec_mode"]:8s} rows {j["config"]["rows_per_gpu"]:>11d} sel {j["config"]["selected_rows_total"]/j["config"]["rows_total"]:.4f} '
           f'step {j["ms_per_step"]:.3f} ms kernel {r["kernel_ms"]:.3f} ms {r["achieved"]:.0f} GB/s frac {r["frac"]:.3f} rows/s {j["value"]:.3e}')
 PY
+timeout -k 10 120 python tools/bench_q6.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_q6.txt
