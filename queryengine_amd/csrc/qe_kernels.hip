@@ -170,6 +170,21 @@ void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, un
 
 // Calibration of SPARSE streaming reads (late materialisation): the same loop, but a lane loads its 16 bytes only when a
 // hash of the vector index falls below `pct` -- what fraction of the dense time does a `pct` % selection cost?
+template <int KIND>
+__device__ __forceinline__ u64x2 sparse_load(const u64x2 *p) {
+    if (KIND == 1) return *p;
+    if (KIND >= 2) {   // cache-policy variants through the ISA bits: 2 = sc0 sc1, 3 = sc1, 4 = sc0, 5 = sc0 sc1 nt
+        u64x2 v;
+        if (KIND == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+        else if (KIND == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+        else if (KIND == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __builtin_nontemporal_load(p);
+}
+
+template <int KIND>
 __global__ void __launch_bounds__(256) stream_read_sparse_kernel(const u64x2 *src, i64 nvec, u64 *sink, unsigned pct) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,8 +199,9 @@ __global__ void __launch_bounds__(256) stream_read_sparse_kernel(const u64x2 *sr
             h *= 0xBF58476D1CE4E5B9ull;
             h ^= h >> 32;
             v[j].x = 0; v[j].y = 0;
-            if ((unsigned)(h % 100u) < pct) v[j] = __builtin_nontemporal_load(src + idx);
+            if ((unsigned)(h % 100u) < pct) v[j] = sparse_load<KIND>(src + idx);
         }
+        if (KIND >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm loads are invisible to the compiler's counters (timing only)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y;
     }
@@ -196,8 +212,19 @@ void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
     static const int sparse_pct = std::getenv("QE_CALIB_SPARSE_PCT") ? std::atoi(std::getenv("QE_CALIB_SPARSE_PCT")) : -1;
-    if (sparse_pct >= 0)
-        hipLaunchKernelGGL(stream_read_sparse_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink, (unsigned)sparse_pct);
+    static const int sparse_kind = std::getenv("QE_CALIB_SPARSE_KIND") ? std::atoi(std::getenv("QE_CALIB_SPARSE_KIND")) : 0;
+    if (sparse_pct >= 0) {
+        const dim3 g(256 * 8), b(256);
+        const u64x2 *sp = (const u64x2 *)src;
+        switch (sparse_kind) {
+        case 1: hipLaunchKernelGGL(stream_read_sparse_kernel<1>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        case 2: hipLaunchKernelGGL(stream_read_sparse_kernel<2>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        case 3: hipLaunchKernelGGL(stream_read_sparse_kernel<3>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        case 4: hipLaunchKernelGGL(stream_read_sparse_kernel<4>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        case 5: hipLaunchKernelGGL(stream_read_sparse_kernel<5>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        default: hipLaunchKernelGGL(stream_read_sparse_kernel<0>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        }
+    }
     else
         hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
 }
