@@ -177,6 +177,7 @@ struct CodegenInput {
     FusedGeometry geo;
     int nontemporal = 1;
     int nt_stores = 1;    // non-temporal stores for the output rows
+    int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
     bool staged = true;   // late materialisation: evaluate the filter's AND chain conjunct by conjunct, load later columns for live rows only
     int debug_mask = 0;   // ablation builds (wrong results): 1 no look-back, 2 no staging stores, 4 no move
 };
