@@ -597,7 +597,9 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
                 nbool += o.nullable ? 1 : 0;
             }
             const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 54;
-            if (est > 300 && in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
+            // three waves per SIMD need <= 168 VGPRs: a half-size sub-tile at 3 waves beat the full one at 2 waves
+            // (cfg 2 with nullable inputs: 4.47 vs 6.16 ms per 1 B rows)
+            if (((est > 168 && in.geo.unroll > 4) || (est > 300 && in.geo.unroll > 2)) && ctx->opts.tuning[1] == 0) {
                 in.geo.unroll /= 2;
                 in.geo.subs_per_chunk *= 2;   // keep the chunk size
                 plan->cg = generate_fused_source(in);
