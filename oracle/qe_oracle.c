@@ -32,11 +32,41 @@ int32_t qo_double_compare(double a, double b) {
 /* java.lang.Double.equals */
 int32_t qo_double_equals(double a, double b) { return double_to_long_bits(a) == double_to_long_bits(b); }
 
-/* java.lang.String.compareTo restricted to what UTF-8 byte order agrees with
- * (all BMP text without surrogates; every string the tests use is ASCII) */
+/* java.lang.String.compareTo (Interpreter.kt:104-107, BytecodeCompiler.kt:303): lexicographic order of the UTF-16 code
+ * units.  UTF-8 byte order agrees with it except that a supplementary character (a surrogate pair 0xD800.. in UTF-16)
+ * sorts BEFORE U+E000..U+FFFF; next_unit() walks a UTF-8 string one UTF-16 unit at a time. */
+typedef struct { const unsigned char *p; uint32_t pending; } u16_iter;
+static int next_unit(u16_iter *it, uint32_t *unit) {
+    if (it->pending) { *unit = it->pending; it->pending = 0; return 1; }
+    const unsigned char *p = it->p;
+    if (!*p) return 0;
+    uint32_t c = p[0], cp = c;
+    int extra = c < 0x80 ? 0 : (c >> 5) == 0x6 ? 1 : (c >> 4) == 0xe ? 2 : (c >> 3) == 0x1e ? 3 : -1, ok = extra >= 0;
+    for (int k = 1; ok && k <= extra; k++) ok = (p[k] & 0xc0) == 0x80;   /* a NUL ends the check: never reads past the end */
+    if (ok) {
+        if (extra > 0) cp = c & (0xffu >> (extra + 2));
+        for (int k = 1; k <= extra; k++) cp = (cp << 6) | (p[k] & 0x3f);
+        it->p += extra + 1;
+    } else {
+        it->p += 1;
+    }
+    if (cp >= 0x10000 && cp <= 0x10ffff) {
+        cp -= 0x10000;
+        *unit = 0xd800 + (cp >> 10);
+        it->pending = 0xdc00 + (cp & 0x3ff);
+    } else {
+        *unit = cp & 0xffff;
+    }
+    return 1;
+}
 static int32_t string_compare(const char *a, const char *b) {
-    int c = strcmp(a, b);
-    return c < 0 ? -1 : (c > 0 ? 1 : 0);
+    u16_iter x = {(const unsigned char *)a, 0}, y = {(const unsigned char *)b, 0};
+    for (;;) {
+        uint32_t ux = 0, uy = 0;
+        const int hx = next_unit(&x, &ux), hy = next_unit(&y, &uy);
+        if (!hx || !hy) return hx == hy ? 0 : (hx ? 1 : -1);
+        if (ux != uy) return ux < uy ? -1 : 1;
+    }
 }
 
 /* Math.min / Math.max (Accumulators.kt:62,80): NaN wins, -0.0 < 0.0 */

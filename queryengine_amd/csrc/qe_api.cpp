@@ -657,6 +657,16 @@ void fill_inputs(FusedParams &p, const qe_batch *batch, const Plan &plan) {
         p.colvalid[s] = (const unsigned long long *)c.validity;
     }
     p.nrows = batch->nrows;
+    // plan constant lookup tables (string ranks / code remaps) ride in the unused tail of col[]
+    if (plan.aux_dev.size() != plan.cg.aux_tables.size()) {
+        for (const std::vector<int32_t> &t : plan.cg.aux_tables) {
+            void *d = nullptr;
+            QE_HIP(hipMalloc(&d, std::max<size_t>(t.size() * 4, 16)));
+            plan.aux_dev.push_back(d);
+            if (!t.empty()) QE_HIP(hipMemcpy(d, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    for (size_t k = 0; k < plan.aux_dev.size(); k++) p.col[kMaxCols - 1 - k] = plan.aux_dev[k];
 }
 
 void launch_fused(qe_ctx *ctx, const Plan &plan, FusedParams &p, int grid) {

@@ -60,6 +60,13 @@ struct DictData {
     }
 };
 
+// java.lang.String.compareTo (BytecodeCompiler.kt:303, Interpreter.kt:104-107) on UTF-8 input: lexicographic order of
+// the UTF-16 code units (a supplementary character sorts as its surrogate pair, i.e. BEFORE U+E000..U+FFFF).
+int utf16_compare(const std::string &a, const std::string &b);
+// Dense ranks of the strings of several lists in ONE merged compareTo order: rank[l][i] of lists[l][i]; equal strings get
+// equal ranks, so every comparison of two strings is the same comparison of their ranks.
+std::vector<std::vector<int32_t>> merged_ranks(const std::vector<const std::vector<std::string> *> &lists);
+
 }  // namespace qe
 
 struct qe_dict {
@@ -188,6 +195,7 @@ struct CodegenOutput {
     std::vector<int> used_cols;  // batch column index per kernel column slot
     bool has_filter = false;
     bool two_pass = false;       // the module also holds qe_fp_count / qe_fp_write (count + direct ordered write)
+    std::vector<std::vector<int32_t>> aux_tables;   // int32 tables indexed by dictionary codes (string ranks, remaps): col[kMaxCols-1-k]
     // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
     // accumulator table geometry: ngroups rows of table_words u64 words {first row, (count, acc) per aggregate}
     std::vector<OutSpec> keys;
@@ -236,6 +244,8 @@ struct Plan {
     Kernel kernel;
     FusedGeometry geo;
     bool aggregate = false;
+    mutable std::vector<void *> aux_dev;      // device copies of cg.aux_tables (uploaded at the first execution)
+    ~Plan() { for (void *q : aux_dev) (void)hipFree(q); }
     mutable double last_selectivity = -1.0;   // kept / scanned rows of the last execution (picks the two-pass form)
 };
 

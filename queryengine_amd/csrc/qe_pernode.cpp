@@ -84,6 +84,20 @@ struct Exec {
         return r;
     }
 
+    // map a STRING code column through a host table (string ranks, code remaps) -> INT32 column
+    std::vector<std::shared_ptr<std::vector<int32_t>>> keep_tables;   // host staging must outlive the async copies
+    Buf lookup(const std::vector<int32_t> &table, const Vec &codes) {
+        auto host = std::make_shared<std::vector<int32_t>>(table);
+        keep_tables.push_back(host);
+        Buf dev = alloc(std::max<size_t>(host->size() * 4, 16));
+        if (!host->empty()) QE_HIP(hipMemcpyAsync(dev.get(), host->data(), host->size() * 4, hipMemcpyHostToDevice, s));
+        Buf out = alloc_col(QE_INT32);
+        pn::lookup_codes(s, (const int32_t *)dev.get(), (int32_t)host->size(), (const int32_t *)codes.data.get(), (int32_t *)out.get(), n);
+        keep_dev.push_back(dev);
+        return out;
+    }
+    std::vector<Buf> keep_dev;
+
     Buf ones() {
         Buf r = alloc_words();
         pn::word_fill(s, ~0ull, (uint64_t *)r.get(), words_of(n));
@@ -153,17 +167,29 @@ struct Exec {
             const int ot = e.nodes[nd.ops[0]].type;
             r.valid = and_valid(a.valid, b.valid);
             if (ot == QE_STRING) {
-                if (cmp != pn::C_EQ && cmp != pn::C_NE)
-                    fail(QE_ERR_UNSUPPORTED, "ordering comparison of STRING values is not supported on the device");
+                const bool eqne = cmp == pn::C_EQ || cmp == pn::C_NE;
                 if (a.is_str_lit && b.is_str_lit) {
+                    const int c = utf16_compare(a.lit, b.lit);
                     r.scalar = true;
-                    r.i = ((a.lit == b.lit) == (cmp == pn::C_EQ)) ? 1 : 0;
+                    r.i = (cmp == pn::C_LT ? c < 0 : cmp == pn::C_LE ? c <= 0 : cmp == pn::C_GE ? c >= 0 : cmp == pn::C_GT ? c > 0
+                           : cmp == pn::C_EQ ? c == 0 : c != 0) ? 1 : 0;
                     return r;
                 }
-                // String.equals against a literal == code equality (absent literal: code -1, never equal)
-                if (a.is_str_lit) { a.i = b.dict->find(a.lit); a.is_str_lit = false; }
-                else if (b.is_str_lit) { b.i = a.dict->find(b.lit); b.is_str_lit = false; }
-                else if (a.dict != b.dict) fail(QE_ERR_UNSUPPORTED, "comparison of STRING values with different dictionaries");
+                if (eqne && (a.is_str_lit || b.is_str_lit)) {
+                    // String.equals against a literal == code equality (absent literal: code -1, never equal)
+                    if (a.is_str_lit) { a.i = b.dict->find(a.lit); a.is_str_lit = false; }
+                    else { b.i = a.dict->find(b.lit); b.is_str_lit = false; }
+                } else if (!(eqne && a.dict == b.dict)) {
+                    // String.compareTo / equals across dictionaries: dense ranks in one merged compareTo order, compared as INT32
+                    const std::vector<std::string> lit_a{a.lit}, lit_b{b.lit};
+                    const std::vector<std::string> *la = a.is_str_lit ? &lit_a : &a.dict->entries;
+                    const std::vector<std::string> *lb = b.is_str_lit ? &lit_b : &b.dict->entries;
+                    std::vector<std::vector<int32_t>> ranks = merged_ranks({la, lb});
+                    if (a.is_str_lit) { a.i = ranks[0][0]; a.is_str_lit = false; }
+                    else { a.data = lookup(ranks[0], a); }
+                    if (b.is_str_lit) { b.i = ranks[1][0]; b.is_str_lit = false; }
+                    else { b.data = lookup(ranks[1], b); }
+                }
                 r.data = alloc_words();
                 pn::compare(s, QE_INT32, cmp, 0, opnd(a), opnd(b), (uint64_t *)r.data.get(), n);
                 return r;
@@ -205,9 +231,21 @@ struct Exec {
                 // unify dictionaries; the codes of a non-literal side stay valid (its dictionary is a prefix)
                 auto ndct = std::make_shared<DictData>();
                 const Vec *base = !t.is_str_lit ? &t : (!f.is_str_lit ? &f : nullptr);
-                if (!t.is_str_lit && !f.is_str_lit && t.dict != f.dict)
-                    fail(QE_ERR_UNSUPPORTED, "IF over STRING values with different dictionaries");
                 if (base) *ndct = *base->dict;
+                if (!t.is_str_lit && !f.is_str_lit && t.dict != f.dict) {
+                    // union dictionary: THEN side's dictionary is its prefix, the ELSE side's codes are remapped
+                    std::vector<int32_t> fmap;
+                    for (const std::string &str : f.dict->entries) {
+                        int32_t code = ndct->find(str);
+                        if (code < 0) {
+                            code = (int32_t)ndct->entries.size();
+                            ndct->entries.push_back(str);
+                            ndct->index[str] = code;
+                        }
+                        fmap.push_back(code);
+                    }
+                    f.data = lookup(fmap, f);
+                }
                 auto resolve = [&](Vec &x) {
                     if (!x.is_str_lit) return;
                     int32_t code = ndct->find(x.lit);

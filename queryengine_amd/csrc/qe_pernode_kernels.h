@@ -43,6 +43,8 @@ void expand_indices(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t
                     uint32_t *indices, int64_t nwords);
 void gather(hipStream_t s, int type, const void *src, const uint32_t *idx, void *out, int64_t m);
 void gather_bits(hipStream_t s, const uint64_t *src, const uint32_t *idx, uint64_t *out, int64_t m);
+// out[i] = table[codes[i]] (a code outside the table -- the garbage under a NULL -- reads as -1): string ranks / code remaps
+void lookup_codes(hipStream_t s, const int32_t *table, int32_t ntable, const int32_t *codes, int32_t *out, int64_t n);
 
 }  // namespace pn
 }  // namespace qe

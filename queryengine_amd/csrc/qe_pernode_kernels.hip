@@ -447,5 +447,17 @@ void gather_bits(hipStream_t s, const uint64_t *src, const uint32_t *idx, uint64
     hipLaunchKernelGGL(k_gather_bits, dim3(grid_for(m)), dim3(256), 0, s, (const u64 *)src, idx, (u64 *)out, (i64)m);
 }
 
+__global__ void __launch_bounds__(256) k_lookup_codes(const int *table, int ntable, const int *codes, int *out, i64 n) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const int c = codes[j];
+        out[j] = (unsigned)c < (unsigned)ntable ? table[c] : -1;
+    }
+}
+void lookup_codes(hipStream_t s, const int32_t *table, int32_t ntable, const int32_t *codes, int32_t *out, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_lookup_codes, dim3(grid_for(n)), dim3(256), 0, s, (const int *)table, (int)ntable, (const int *)codes, (int *)out, (i64)n);
+}
+
 }  // namespace pn
 }  // namespace qe

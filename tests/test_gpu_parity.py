@@ -347,3 +347,24 @@ def test_random_conjunctive_filters(any_ctx, oracle, seed):
             flt = fn(Fn.AND, flt, g.boolean(2), t=B) if rnd.random() < 0.5 else fn(Fn.AND, g.boolean(2), flt, t=B)
         projs = [g.numeric(2) if rnd.random() < 0.7 else g.boolean(2) for _ in range(rnd.randint(1, 3))]
         run_both(any_ctx, oracle, cols, flt, projs)
+
+
+def test_string_ordering_and_cross_dictionary_comparisons(any_ctx, oracle):
+    """String.compareTo on the device (BytecodeCompiler.kt:300-306): all six comparisons of a dictionary column with a
+    literal, with a column of the SAME dictionary and with a column of a DIFFERENT dictionary (ranks in one merged
+    UTF-16 order), plus IF over two dictionaries (union dictionary, remapped codes); nulls on both sides."""
+    rng = np.random.default_rng(21)
+    n = 30_011
+    d1 = ["pear", "apple", "fig", "Fig", "", "zebra", "～", "\U0001F600", "apples", "é"]
+    d2 = ["fig", "banana", "\U0001F600", "apple", "kiwi", "zebra ", "A"]
+    s1 = random_column(rng, S, n, null_frac=0.1, dictionary=d1)
+    s2 = random_column(rng, S, n, null_frac=0.1, dictionary=d1)
+    t = random_column(rng, S, n, null_frac=0.1, dictionary=d2)
+    v = Column(D, rng.random(n))
+    S1, S2, T, V = col("s1", 0, S), col("s2", 1, S), col("t", 2, S), col("v", 3, D)
+    cols = [s1, s2, t, v]
+    lit = StringLiteralExpression
+    for f in (Fn.CMP_LT, Fn.CMP_LE, Fn.CMP_GE, Fn.CMP_GT, Fn.CMP_EQ, Fn.CMP_NE):
+        run_both(any_ctx, oracle, cols, fn(f, S1, lit("fig")), [S1, fn(f, lit("b"), S1), fn(f, S1, S2), fn(f, S1, T), fn(f, T, lit("～"))])
+    run_both(any_ctx, oracle, cols, fn(Fn.AND, fn(Fn.CMP_GE, S1, T), fn(Fn.CMP_LT, T, lit("kiwi"))),
+             [fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), S1, T), fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.3)), T, S2), V])

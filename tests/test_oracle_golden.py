@@ -164,3 +164,21 @@ def test_columnar_cpu_baseline_matches_the_oracle(oracle):
         o0, o1, used = oracle.columnar_config2(cols[0].data, cols[1].data, cols[2].data, 100.0, 0.5, threads)
         assert used == threads
         assert np.array_equal(o0, want[0].data) and np.array_equal(o1.view(np.uint64), want[1].data.view(np.uint64))
+
+
+def test_string_compare_is_java_compare_to(oracle):
+    """String.compareTo = lexicographic order of UTF-16 code units (Interpreter.kt:104-107, BytecodeCompiler.kt:303):
+    a supplementary character is a surrogate pair (0xD83D 0xDE00) and sorts BEFORE U+FF5E, which UTF-8 byte order and
+    code-point order both get wrong.  Self-derived vectors (the reference's tests hold no string ordering case)."""
+    from queryengine_amd import FunctionExpression, Function, StringLiteralExpression, DataType
+    B = DataType.BOOLEAN
+
+    def lt(a, b):
+        return oracle.eval_row(FunctionExpression(Function.CMP_LT, [StringLiteralExpression(a), StringLiteralExpression(b)], B), [])
+
+    ordered = ["", "A", "B", "a", "ab", "b", "é", "\U0001F600", "～"]     # ascending in UTF-16 order
+    for i, x in enumerate(ordered):
+        for j, y in enumerate(ordered):
+            assert lt(x, y) == (i < j), (x, y)
+    py = sorted(ordered, key=lambda s: s.encode("utf-16-be", "surrogatepass"))
+    assert py == ordered
