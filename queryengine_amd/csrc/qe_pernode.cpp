@@ -334,6 +334,9 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         QE_HIP(hipGetLastError());
         QE_HIP(hipStreamSynchronize(x.s));
         m = (int64_t)ctx->h_ctrl[1];
+        if (ctx->opts.result_capacity_rows > 0 && m > ctx->opts.result_capacity_rows)   // same contract as the fused path
+            fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(m) + " rows but result_capacity_rows is " +
+                                         std::to_string(ctx->opts.result_capacity_rows));
         Buf idx = x.alloc((size_t)std::max<int64_t>(m, 1) * 4);
         pn::expand_indices(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
                            (const uint32_t *)offsets.get(), (uint32_t *)idx.get(), nw);

@@ -368,3 +368,31 @@ def test_string_ordering_and_cross_dictionary_comparisons(any_ctx, oracle):
         run_both(any_ctx, oracle, cols, fn(f, S1, lit("fig")), [S1, fn(f, lit("b"), S1), fn(f, S1, S2), fn(f, S1, T), fn(f, T, lit("～"))])
     run_both(any_ctx, oracle, cols, fn(Fn.AND, fn(Fn.CMP_GE, S1, T), fn(Fn.CMP_LT, T, lit("kiwi"))),
              [fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.5)), S1, T), fn(Fn.IF, fn(Fn.CMP_LT, V, num(0.3)), T, S2), V])
+
+
+@pytest.mark.parametrize("form", ["single_pass", "two_pass", "per_node"])
+def test_result_capacity_rows_bounds_the_output_buffers(oracle, form):
+    """qe_options.result_capacity_rows: output buffers are sized for that many rows; a result that fits is exact, one that
+    does not is an error (status QE_ERR_INVALID_ARG), never a silent truncation -- and the context stays usable."""
+    from queryengine_amd import workloads as W
+    n = 100_000
+    wl = W.config2(n, null_pct=1)                       # ~4.9 % -> about 4 900 rows
+    kw = {"single_pass": dict(), "two_pass": dict(tuning=[0, 0, 0, 0, 0, 512, 0, 0]), "per_node": dict(exec_mode=N.EXEC_PER_NODE)}[form]
+    for cap, fits in ((6000, True), (3000, False)):
+        ctx = E.Context(device=0, result_capacity_rows=cap, **kw)
+        batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
+        host = [batch.column_to_host(j) for j in range(batch.ncols)]
+        want = oracle.filter_project(host, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+        cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
+        for _ in range(2):
+            if fits:
+                res = E.filter_project(ctx, batch, cf, cp)
+                for g, w in zip(res.to_columns(), want):
+                    assert_columns_equal(g, w, f"cap {cap}")
+                res.free()
+            else:
+                with pytest.raises(N.QeError) as ei:
+                    E.filter_project(ctx, batch, cf, cp)
+                assert "result_capacity_rows" in str(ei.value)
+        batch.free()
+        ctx.close()
