@@ -495,8 +495,10 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     const int mw = ctx->opts.tuning[3] / 100;    // tuning[3] = 100 * min_waves + blocks_per_cu
     if (mw >= 1 && mw <= 8) g.min_waves = mw;
     if (u >= 1 && u <= 16) g.unroll = u;
-    const int spc = ctx->opts.tuning[4];
+    const int spc = ctx->opts.tuning[4] % 10000;   // tuning[4] = subs_per_chunk + 10000 * (LDS ring entries / 256)
     if (spc >= 1 && spc <= 4096) g.subs_per_chunk = spc;
+    const int ringk = ctx->opts.tuning[4] / 10000;
+    if (ringk == 1 || ringk == 2 || ringk == 4) g.ring_entries = 256 * ringk;
     const int lbk = ctx->opts.tuning[6] % 100;   // tuning[6] = lookback_k + 100 * gate_period_log2 + 10000 * gate_width_log2
     if (lbk >= 1 && lbk <= 16) g.lookback_k = lbk;
     const int gp = (ctx->opts.tuning[6] / 100) % 100, gw = ctx->opts.tuning[6] / 10000;
@@ -514,7 +516,7 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
 
 std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load,
-                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0) {
+                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false) {
     if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
     CodegenInput in;
     in.filter = filter ? &filter->e : nullptr;
@@ -532,6 +534,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     }
     in.cmp_semantics = ctx->opts.cmp_semantics;
     in.geo = geometry_of(ctx);
+    if (wide) {   // the second candidate of the geometry choice (qe_ctx::geo_choice)
+        in.geo.unroll = 16;
+        in.geo.subs_per_chunk = 4;
+        in.geo.ring_entries = 512;
+    }
     in.nontemporal = ctx->opts.tuning[2] % 10 == 2 ? 0 : 1;
     in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
     in.debug_mask = ctx->opts.tuning[5] & 255;   // bits 256.. are host-side switches, not ablation builds
@@ -539,7 +546,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.filter_load_stages = (ctx->opts.tuning[5] & 4096) ? 1 : 0;   // bit 4096: every filter column in the first load stage   // bit 2048: load every column for every row (no late materialisation)
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (const void *)c.dict.get() << ",";
@@ -599,7 +606,8 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
             const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 54;
             // three waves per SIMD need <= 168 VGPRs: a half-size sub-tile at 3 waves beat the full one at 2 waves
             // (cfg 2 with nullable inputs: 4.47 vs 6.16 ms per 1 B rows)
-            if (((est > 168 && in.geo.unroll > 4) || (est > 300 && in.geo.unroll > 2)) && ctx->opts.tuning[1] == 0) {
+            plan->est_regs = est;
+            if (((est > 168 && in.geo.unroll > 4) || (est > 300 && in.geo.unroll > 2)) && ctx->opts.tuning[1] == 0 && !wide) {
                 in.geo.unroll /= 2;
                 in.geo.subs_per_chunk *= 2;   // keep the chunk size
                 plan->cg = generate_fused_source(in);
@@ -626,6 +634,8 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         }
     }
     plan->geo = in.geo;
+    plan->explicit_geometry = ctx->opts.tuning[0] != 0 || ctx->opts.tuning[1] != 0 || ctx->opts.tuning[3] != 0 || ctx->opts.tuning[4] != 0 ||
+                              ctx->opts.tuning[7] != 0;
     plan->aggregate = agg_fns != nullptr;
     plan->kernel = ctx->jit->get(plan->cg.source, "qe_fused", load);
     ctx->plans[k] = plan;
@@ -669,11 +679,12 @@ void fill_inputs(FusedParams &p, const qe_batch *batch, const Plan &plan) {
     for (size_t k = 0; k < plan.aux_dev.size(); k++) p.col[kMaxCols - 1 - k] = plan.aux_dev[k];
 }
 
-void launch_fused(qe_ctx *ctx, const Plan &plan, FusedParams &p, int grid) {
+void launch_fused(qe_ctx *ctx, const Plan &plan, FusedParams &p, int grid, bool timed = false) {
     void *args[] = {&p};
-    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    timed = timed || ctx->opts.profile;
+    if (timed) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     QE_HIP(hipModuleLaunchKernel(plan.kernel.fn, grid, 1, 1, plan.geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
-    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    if (timed) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
 }
 
 void collect_time(qe_ctx *ctx) {
@@ -705,6 +716,23 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
                      int32_t nproj) {
     auto plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true);
     const int64_t n = batch->nrows;
+    // Geometry choice ("measure, don't guess"): which of the two sub-tile geometries is faster depends on the plan's
+    // shape (cfg 2: the wide one by 5-8 %; cfg 3: the default by 25 %), so on a large batch the first two executions of a
+    // plan time one each and the faster one is kept.  Same rows, same order either way.
+    const std::shared_ptr<Plan> base = plan;
+    qe_ctx::GeoChoice *choice = nullptr;
+    int cand = 0;
+    {
+        const int k2 = plan->geo.unroll > 0 ? (plan->est_regs - 54) / (2 * plan->geo.unroll) : 99;   // registers per row pair
+        const bool eligible = plan->cg.has_filter && !plan->explicit_geometry && plan->est_regs > 0 && n >= (32ll << 20) &&
+                              32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0;
+        if (eligible) {
+            choice = &ctx->geo_choice[base.get()];
+            cand = choice->chosen >= 0 ? choice->chosen : (choice->runs[0] <= choice->runs[1] ? 0 : 1);
+            if (cand == 1) plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true);
+        }
+    }
+    const bool exploring = choice && choice->chosen < 0;
     std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(),
                                                                       [ctx](qe_result *r) { free_result(ctx, r); });
     int64_t cap = ctx->opts.result_capacity_rows > 0 ? std::min<int64_t>(ctx->opts.result_capacity_rows, n) : n;
@@ -739,7 +767,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     // LDS ring, no staging round trip (which costs 48 B per kept row instead of 16 once the ring overflows).
     const bool force_two_pass = (ctx->opts.tuning[5] & 512) != 0, never_two_pass = (ctx->opts.tuning[5] & 1024) != 0;
     const bool two_pass = plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
-                          (force_two_pass || plan->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6
+                          (force_two_pass || base->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6
     unsigned long long total = 0;
     if (two_pass) {
         const int64_t chunk_rows = plan->geo.chunk_rows();
@@ -839,10 +867,17 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         // flags, tickets and descriptors are re-zeroed on the stream before EVERY launch
         QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
         QE_HIP(hipMemsetAsync(desc, 0, desc_words * 8, ctx->stream));
-        launch_fused(ctx, *plan, p, grid);
+        launch_fused(ctx, *plan, p, grid, exploring);
         QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
         QE_HIP(hipStreamSynchronize(ctx->stream));
         collect_time(ctx);
+        if (exploring) {   // one timed execution per candidate, then the faster geometry is kept for this plan
+            float ms = 0.f;
+            QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            choice->best_ms[cand] = std::min(choice->best_ms[cand], ms);
+            choice->runs[cand]++;
+            if (choice->runs[0] >= 1 && choice->runs[1] >= 1) choice->chosen = choice->best_ms[1] < choice->best_ms[0] ? 1 : 0;
+        }
         if ((ctx->opts.tuning[5] & 32) && std::getenv("QE_TRACE_FILE")) {
             std::vector<unsigned long long> tr((size_t)nchunks * 4);
             QE_HIP(hipMemcpy(tr.data(), p.trace, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -858,7 +893,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
         total = ctx->h_ctrl[1];
     }
-    plan->last_selectivity = (double)total / (double)n;
+    plan->last_selectivity = base->last_selectivity = (double)total / (double)n;
     if ((int64_t)total > cap)
         fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(total) + " rows but result_capacity_rows is " +
                                      std::to_string(cap));
@@ -913,8 +948,14 @@ int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_e
     if (!ctx || !batch) return QE_ERR_INVALID_ARG;
     return guarded(ctx, [&] {
         if (ctx->device >= 0) need_device(ctx);
-        if (ctx->opts.exec_mode == QE_EXEC_FUSED)
-            (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0);
+        if (ctx->opts.exec_mode == QE_EXEC_FUSED) {
+            auto pl = get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0);
+            // the second geometry candidate (qe_ctx::geo_choice) is compiled ahead of time as well, so that the choice on
+            // the device never waits for the JIT
+            const int k2 = pl->geo.unroll > 0 ? (pl->est_regs - 54) / (2 * pl->geo.unroll) : 99;
+            if (pl->cg.has_filter && !pl->explicit_geometry && pl->est_regs > 0 && 32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0)
+                (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
+        }
     });
 }
 

@@ -247,6 +247,8 @@ struct Plan {
     mutable std::vector<void *> aux_dev;      // device copies of cg.aux_tables (uploaded at the first execution)
     ~Plan() { for (void *q : aux_dev) (void)hipFree(q); }
     mutable double last_selectivity = -1.0;   // kept / scanned rows of the last execution (picks the two-pass form)
+    int est_regs = 0;                         // register estimate of the plan's geometry (get_plan)
+    bool explicit_geometry = false;           // unroll / chunk / ring were fixed through qe_options.tuning
 };
 
 // kernel parameter block of the generated fused kernel (must match the prelude in qe_codegen.cpp)
@@ -285,6 +287,10 @@ struct qe_ctx {
     qe::Pool pool;
     std::unique_ptr<qe::Jit> jit;
     std::map<std::string, std::shared_ptr<qe::Plan>> plans;
+    // geometry choice per fused filter+project plan: the first executions on a large batch time the default geometry and
+    // the "wide" one (16 load groups per sub-tile, 512-entry LDS rings, 2 waves per SIMD); the faster one is kept
+    struct GeoChoice { int chosen = -1; int runs[2] = {0, 0}; float best_ms[2] = {1e30f, 1e30f}; };
+    std::map<const qe::Plan *, GeoChoice> geo_choice;
     std::string source_scratch;
     // profiling of the dominant kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

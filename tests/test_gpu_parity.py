@@ -396,3 +396,43 @@ def test_result_capacity_rows_bounds_the_output_buffers(oracle, form):
                 assert "result_capacity_rows" in str(ei.value)
         batch.free()
         ctx.close()
+
+
+def _workload_vs_oracle(ctx, oracle, wl, n, reps=1):
+    batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
+    host = [batch.column_to_host(j, dictionary=getattr(c, "dictionary", None)) for j, c in enumerate(wl.columns)]
+    want = oracle.filter_project(host, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+    cf = ctx.compile(wl.filter) if wl.filter is not None else None
+    cp = [ctx.compile(p) for p in wl.projections]
+    for rep in range(reps):
+        res = E.filter_project(ctx, batch, cf, cp)
+        got = res.to_columns()
+        assert res.count == len(want[0])
+        for g, w in zip(got, want):
+            assert_columns_equal(g, w, f"{wl.name} n={n} rep {rep}")
+        res.free()
+    batch.free()
+
+
+def test_wide_geometry_parity(oracle):
+    """The second sub-tile geometry of the fused kernel (16 load groups per sub-tile, 512-entry LDS rings, 4 sub-tiles per
+    chunk), pinned through qe_options.tuning: ragged sizes, several chunks, low and high selectivity, dictionary shape."""
+    from queryengine_amd import workloads as W
+    ctx = E.Context(device=0, tuning=[256, 16, 0, 0, 20004])
+    for n in (1, 2047, 2048, 2049, 8191, 8192, 70_001, 300_000):
+        _workload_vs_oracle(ctx, oracle, W.config2(n), n)
+    for a_limit, c_limit in ((1000, 1.0), (1000, 0.5), (10, 0.5)):
+        _workload_vs_oracle(ctx, oracle, W.config2(150_001, a_limit=a_limit, c_limit=c_limit), 150_001)
+    _workload_vs_oracle(ctx, oracle, W.config4(200_003), 200_003)
+    _workload_vs_oracle(ctx, oracle, W.config1(100_000), 100_000)
+    ctx.close()
+
+
+def test_geometry_choice_on_a_large_batch(oracle):
+    """From 32 Mi rows on, the first two executions of a plan time the two geometries and the faster one is kept: every
+    execution -- exploring or settled -- returns exactly the oracle's rows."""
+    from queryengine_amd import workloads as W
+    n = 34_000_001
+    ctx = E.Context(device=0)
+    _workload_vs_oracle(ctx, oracle, W.config2(n), n, reps=4)
+    ctx.close()
