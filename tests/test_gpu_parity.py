@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): bit-exact for integer / bitmap / index results; 
 also required to be bit-exact here (0 ULP, tighter than the 1 ULP allowed) because the generated
 kernels are compiled with -ffp-contract=off.
 """
+import os
 import random
 
 import numpy as np
@@ -192,7 +193,7 @@ def test_q6_shape(any_ctx, oracle):
     assert 0 < len(got[0]) < n * 0.05
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + int(os.environ.get("QE_FUZZ_EXTRA", "0"))))
 def test_random_expression_trees(any_ctx, oracle, seed):
     """Differential test in the spirit of CompilerTest's @EnumSource(Mode): random typed trees,
     null-heavy data with NaN/-0.0/extreme integers, GPU vs oracle."""
@@ -328,7 +329,7 @@ def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 + int(os.environ.get("QE_FUZZ_EXTRA", "0"))))
 def test_random_conjunctive_filters(any_ctx, oracle, seed):
     """Filters that ARE top-level AND chains of 2-4 random boolean trees over null-heavy columns, several chunks of rows:
     the staged (late-materialisation) evaluation -- a conjunct is only evaluated, and its columns only loaded, for rows
