@@ -724,7 +724,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     int cand = 0;
     {
         const int k2 = plan->geo.unroll > 0 ? (plan->est_regs - 54) / (2 * plan->geo.unroll) : 99;   // registers per row pair
-        const bool eligible = plan->cg.has_filter && !plan->explicit_geometry && plan->est_regs > 0 && n >= (32ll << 20) &&
+        const bool eligible = !plan->explicit_geometry && plan->est_regs > 0 && n >= (32ll << 20) &&   // (a plain projection too: 6.5 vs 7.3 ms)
                               32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0;
         if (eligible) {
             choice = &ctx->geo_choice[base.get()];
@@ -953,7 +953,7 @@ int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_e
             // the second geometry candidate (qe_ctx::geo_choice) is compiled ahead of time as well, so that the choice on
             // the device never waits for the JIT
             const int k2 = pl->geo.unroll > 0 ? (pl->est_regs - 54) / (2 * pl->geo.unroll) : 99;
-            if (pl->cg.has_filter && !pl->explicit_geometry && pl->est_regs > 0 && 32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0)
+            if (!pl->explicit_geometry && pl->est_regs > 0 && 32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0)
                 (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
         }
     });

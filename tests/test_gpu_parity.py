@@ -436,4 +436,7 @@ def test_geometry_choice_on_a_large_batch(oracle):
     n = 34_000_001
     ctx = E.Context(device=0)
     _workload_vs_oracle(ctx, oracle, W.config2(n), n, reps=4)
+    plain = W.config2(n)
+    plain.filter = None                                   # a projection without a Filter takes part in the choice too
+    _workload_vs_oracle(ctx, oracle, plain, n, reps=3)
     ctx.close()
