@@ -219,3 +219,43 @@ def test_group_by_large_domain_matches_oracle(case, oracle):
                     assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
     batch.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("path", ["lds", "partitioned", "global_atomics"])
+def test_group_by_counter_sharing_with_mixed_nullability(path, oracle):
+    """Aggregates over non-nullable inputs share ONE row counter per group, nullable ones keep their own: every order
+    and mix of the two kinds must finish to the reference's accumulators (COUNT / AVG / empty => null included)."""
+    import itertools
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(31)
+    n = 120_001
+    nkeys = 12 if path == "lds" else 4000
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 256, 0, 0] if path == "global_atomics" else [])
+    d = ["k%05d" % i for i in range(nkeys)]
+    s = Column(S, rng.integers(0, nkeys, n).astype(np.int32), rng.random(n) > 0.02, d)
+    x = Column(D, np.round(rng.normal(0, 50, n)), rng.random(n) > 0.3)          # nullable, integer valued
+    y = Column(I64, rng.integers(-100, 100, n))                                # non-nullable
+    z = Column(D, np.round(rng.normal(0, 5, n)))                               # non-nullable
+    Sx, X, Y, Z = ColumnExpression("s", 0, S), ColumnExpression("x", 1, D), ColumnExpression("y", 2, I64), ColumnExpression("z", 3, D)
+    pool = [(X, oracle.SUM), (Y, oracle.COUNT), (X, oracle.COUNT), (Z, oracle.AVG), (Y, oracle.MIN), (X, oracle.MAX), (Z, oracle.SUM)]
+    flt = FunctionExpression(Function.CMP_LT, [Z, NumericLiteralExpression(4.0)], B)
+    batch = E.DeviceBatch.from_columns(ctx, [s, x, y, z])
+    picks = [pool, pool[::-1], pool[1:4], [pool[1]], [pool[2]], pool[3:6]] + [list(p) for p in itertools.islice(itertools.permutations(pool, 3), 7, 60, 13)]
+    for sel in picks:
+        exprs, aggs = [e for e, _ in sel], [a for _, a in sel]
+        res = E.filter_groupby(ctx, batch, ctx.compile(flt), [ctx.compile(Sx)], [ctx.compile(e) for e in exprs], aggs)
+        cols = res.to_columns()
+        got = [[c.value(i) for c in cols] for i in range(res.count)]
+        res.free()
+        want = oracle.filter_groupby([s, x, y, z], flt, [Sx], exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g[0] == w[0]
+            for a, b, f in zip(g[1:], w[1:], aggs):
+                if b is None or f != oracle.AVG:
+                    assert a == b, (g, w, aggs)
+                else:
+                    assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+    batch.free()
+    ctx.close()
