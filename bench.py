@@ -114,7 +114,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)   # the first two executions of a plan also time its two kernel geometries
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's BASELINE size, 1e9 for config2)")
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

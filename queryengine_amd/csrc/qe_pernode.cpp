@@ -12,6 +12,7 @@
 #include "qe_pernode.h"
 
 #include <algorithm>
+#include <cmath>
 #include <functional>
 
 #include "qe_pernode_kernels.h"
@@ -161,10 +162,42 @@ struct Exec {
             return r;
         }
         case QE_FN_CMP_LT: case QE_FN_CMP_LE: case QE_FN_CMP_GE: case QE_FN_CMP_GT: case QE_FN_CMP_EQ: case QE_FN_CMP_NE: {
-            Vec a = eval(e, nd.ops[0]), b = eval(e, nd.ops[1]);
             const int cmp = nd.fn == QE_FN_CMP_LT ? pn::C_LT : nd.fn == QE_FN_CMP_LE ? pn::C_LE : nd.fn == QE_FN_CMP_GE ? pn::C_GE
                           : nd.fn == QE_FN_CMP_GT ? pn::C_GT : nd.fn == QE_FN_CMP_EQ ? pn::C_EQ : pn::C_NE;
             const int ot = e.nodes[nd.ops[0]].type;
+            if (ot == QE_DOUBLE) {
+                // (double)int_column OP integral literal, |L| <= 2^53: the conversion is monotone and L is exact, so the
+                // comparison can be done on the integers -- no cast kernel, no 8-byte temporary (same rule as Gen::emit)
+                auto int_child = [&](int id) {
+                    const Node &x = e.nodes[id];
+                    if (x.kind != N_CAST || x.type != QE_DOUBLE) return -1;
+                    const Node &c = e.nodes[x.ops[0]];
+                    return ((c.type == QE_INT64 || c.type == QE_INT32) && c.kind != N_NUM) ? x.ops[0] : -1;
+                };
+                auto int_lit = [&](int id, int ctype, long long &v) {
+                    const Node &x = e.nodes[id];
+                    if (x.kind != N_NUM || x.num != std::floor(x.num) || std::fabs(x.num) > 9007199254740992.0) return false;
+                    v = (long long)x.num;
+                    return ctype == QE_INT64 || (v >= -2147483648ll && v <= 2147483647ll);
+                };
+                const int ia = int_child(nd.ops[0]), ib = int_child(nd.ops[1]);
+                long long lit = 0;
+                const bool left = ia >= 0 && int_lit(nd.ops[1], e.nodes[ia].type, lit);
+                const bool right = !left && ib >= 0 && int_lit(nd.ops[0], e.nodes[ib].type, lit);
+                if (left || right) {
+                    Vec col = eval(e, left ? ia : ib), k;
+                    if (!col.scalar) {
+                        k.type = col.type;
+                        k.scalar = true;
+                        k.i = lit;
+                        r.valid = col.valid;
+                        r.data = alloc_words();
+                        pn::compare(s, col.type, cmp, 0, left ? opnd(col) : opnd(k), left ? opnd(k) : opnd(col), (uint64_t *)r.data.get(), n);
+                        return r;
+                    }
+                }
+            }
+            Vec a = eval(e, nd.ops[0]), b = eval(e, nd.ops[1]);
             r.valid = and_valid(a.valid, b.valid);
             if (ot == QE_STRING) {
                 const bool eqne = cmp == pn::C_EQ || cmp == pn::C_NE;
