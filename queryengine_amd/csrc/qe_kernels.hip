@@ -173,6 +173,12 @@ void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, un
 template <int KIND>
 __device__ __forceinline__ u64x2 sparse_load(const u64x2 *p) {
     if (KIND == 1) return *p;
+    if (KIND == 6) {   // 8-byte loads (what a 4-byte column's 2 rows per lane use): HALF the bytes of the 16-byte form
+        u64x2 v;
+        v.x = __builtin_nontemporal_load((const u64 *)p);
+        v.y = 0;
+        return v;
+    }
     if (KIND >= 2) {   // cache-policy variants through the ISA bits: 2 = sc0 sc1, 3 = sc1, 4 = sc0, 5 = sc0 sc1 nt
         u64x2 v;
         if (KIND == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(256) stream_read_sparse_kernel(const u64x2 *sr
             h *= 0xBF58476D1CE4E5B9ull;
             h ^= h >> 32;
             v[j].x = 0; v[j].y = 0;
-            if ((unsigned)(h % 100u) < pct) v[j] = sparse_load<KIND>(src + idx);
+            if ((unsigned)(h % 100u) < pct) v[j] = sparse_load<KIND>(KIND == 6 ? (const u64x2 *)((const u64 *)src + idx) : src + idx);   // 6: contiguous 8 B per lane
         }
         if (KIND >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the asm loads are invisible to the compiler's counters (timing only)
 #pragma unroll
@@ -222,6 +228,7 @@ void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned
         case 3: hipLaunchKernelGGL(stream_read_sparse_kernel<3>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
         case 4: hipLaunchKernelGGL(stream_read_sparse_kernel<4>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
         case 5: hipLaunchKernelGGL(stream_read_sparse_kernel<5>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
+        case 6: hipLaunchKernelGGL(stream_read_sparse_kernel<6>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
         default: hipLaunchKernelGGL(stream_read_sparse_kernel<0>, g, b, 0, s, sp, nvec, (u64 *)sink, (unsigned)sparse_pct); break;
         }
     }
