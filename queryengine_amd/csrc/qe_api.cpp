@@ -504,7 +504,7 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
     const int gp = (ctx->opts.tuning[6] / 100) % 100, gw = ctx->opts.tuning[6] / 10000;
     if (gp >= 8 && gp <= 24 && gw >= 4 && gw < gp) { g.gate_period_log2 = gp; g.gate_width_log2 = gw; }
     const int pm = ctx->opts.tuning[2] / 10;   // tuning[2] = 10 * (prio_mode + 1) + nt ; 0 = default
-    if (pm >= 1 && pm <= 3) g.prio_mode = pm - 1;
+    if (pm >= 1 && pm <= 4) g.prio_mode = pm - 1;   // 0 none, 1 per sub-tile mod 3, 2 per chunk mod 3, 3 per sub-tile mod 2
     const int nb = ctx->opts.tuning[7] / 100;   // tuning[7] = 100 * nbuf + (stagger / resolve_at code)
     if (nb >= 2 && nb <= 8) g.nbuf = nb;
     const int st7 = ctx->opts.tuning[7] % 100;
