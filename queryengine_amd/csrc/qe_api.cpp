@@ -729,7 +729,14 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         if (eligible) {
             choice = &ctx->geo_choice[base.get()];
             cand = choice->chosen >= 0 ? choice->chosen : (choice->runs[0] <= choice->runs[1] ? 0 : 1);
-            if (cand == 1) plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true);
+            if (cand == 1) {
+                try {
+                    plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true);
+                } catch (const Error &) {   // the wide candidate does not build for this plan: the default stays
+                    choice->chosen = 0;
+                    cand = 0;
+                }
+            }
         }
     }
     const bool exploring = choice && choice->chosen < 0;
@@ -954,7 +961,10 @@ int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_e
             // the device never waits for the JIT
             const int k2 = pl->geo.unroll > 0 ? (pl->est_regs - 54) / (2 * pl->geo.unroll) : 99;
             if (!pl->explicit_geometry && pl->est_regs > 0 && 32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0)
-                (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
+                try {
+                    (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
+                } catch (const Error &) {   // optional candidate: the default plan above is what prepare guarantees
+                }
         }
     });
 }
