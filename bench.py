@@ -3,13 +3,21 @@
 
 A "step" is one pass of the hot path -- qe_filter_project through the C ABI -- over one
 HBM-resident synthetic batch (config 2: SELECT a + b, c * 2.0 FROM t WHERE a < 100 AND c < 0.5,
-int64/int64/f64, 1 B rows per GPU).  Inputs are generated on the device before the timed region.
-Multi-GPU: one process per GPU, rows range-sharded by global row index, no data-path collective
-during the scan (weak scaling: each rank owns --rows rows).
+int64/int64/f64).  Inputs are generated on the device before the timed region.
+
+Rows per GPU (unless --rows is given):
+  N = 1   the configuration BASELINE.json's metric is quoted on: 1 B rows (configs[1]).
+  N > 1   BASELINE.json configs[4] ("cfg 5"): 10 B rows range-sharded over 8 GPUs = 1.25 B rows per GPU.  The SAME shard
+          size is used at N = 2 and 4 (2.5 B / 5 B rows in all), so per-GPU work is fixed as N grows (weak scaling) and
+          N = 8 is exactly cfg 5.  Rank r owns global rows [r * rows, (r + 1) * rows); no data-path collective during
+          the scan.  The materialising exchange (qe_gather: RCCL through the C ABI) is timed separately and reported
+          in "gather" (with and without it); `value` is the scan, which is what a plan whose root consumes its
+          shard in place (an aggregation) pays.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -110,18 +118,44 @@ def cpu_baseline(workload, budget_s=12.0):
                       f"{total:.1f} s on 1 host core"}
 
 
+CFG5_ROWS_PER_GPU = 10_000_000_000 // 8      # BASELINE.json configs[4]
+
+
+def traffic_key(workload: str, rows: int, selectivity, exec_mode: str) -> str:
+    return f"{workload}|rows={rows}|sel={'default' if selectivity is None else format(selectivity, 'g')}|{exec_mode}"
+
+
+def code_hash(ctx, E, batch, cf, cp, exec_mode: str) -> str:
+    """Identity of the code a traffic measurement belongs to: the generated kernel source (fused) or the per-node sources."""
+    if exec_mode == "fused":
+        return hashlib.sha1(E.generated_source(ctx, batch, cf, cp).encode()).hexdigest()[:16]
+    h = hashlib.sha1()
+    for f in ("qe_pernode.cpp", "qe_pernode_kernels.hip"):
+        h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return 0.0 if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)   # the first two executions of a plan also time its two kernel geometries
-    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: the workload's BASELINE size, 1e9 for config2)")
+    ap.add_argument("--warmup", type=int, default=5)   # the first executions of a plan also time its kernel geometries
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: see the module docstring)")
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tuning", default="", help="comma separated kernel tuning knobs (threads,unroll,nt,blocks_per_cu)")
+    ap.add_argument("--tuning", default="", help="comma separated kernel tuning knobs (qe_options.tuning, DESIGN.md 3.1a)")
     ap.add_argument("--exec-mode", default="fused", choices=["fused", "per_node"])
     ap.add_argument("--selectivity", type=float, default=None, help="config2 only: target selectivity (changes the literals)")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the result to rank 0")
+    ap.add_argument("--gather", action="store_true", help="time the materialising exchange too (default when --gpus > 1)")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="under rocprofv3: exactly warmup + steps passes of the hot path and nothing else on the device")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,6 +188,8 @@ def main():
 
     if args.rows is None:
         args.rows = W.WORKLOADS[args.workload]().default_rows
+        if world > 1 and args.workload == "config2":
+            args.rows = CFG5_ROWS_PER_GPU
     wl = W.WORKLOADS[args.workload](args.rows)
     if args.selectivity is not None and args.workload == "config2":
         # a < 1000 * s / c_limit with c < c_limit: sweep 1 %, 10 %, 50 %, 100 % as BASELINE.md section 3 asks
@@ -185,10 +221,16 @@ def main():
     for _ in range(args.warmup):
         nout = step()
     ctx.reset_kernel_time()
+    step_ms, kern_ms = [], []
     barrier()
     t0 = time.perf_counter()
+    tprev = t0
     for _ in range(args.steps):
-        nout = step()
+        nout = step()                              # ends with the result count on the host: a step boundary is a sync
+        tnow = time.perf_counter()
+        step_ms.append((tnow - tprev) * 1e3)
+        tprev = tnow
+        kern_ms.append(ctx.kernel_time()[0])
     barrier()
     dt = time.perf_counter() - t0
     _, kernel_ms_total, launches = ctx.kernel_time()
@@ -201,54 +243,98 @@ def main():
     dt_max = float(t.item())
     total_out = int(cnt.item())
 
+    # the materialising exchange (cfg 5: "with and without the RCCL gather"); never part of `value`
     gather_info = None
-    if args.gather:
-        from queryengine_amd import distributed as QD
-        gather_info = QD.time_gather(ctx, batch, cf, cp, world, rank)
+    if (args.gather or world > 1) and not args.no_gather and not args.profile_run and not rehearsal:
+        try:
+            from queryengine_amd import distributed as QD
+            if world > 1:
+                QD.comm_init(ctx)
+            else:
+                ctx.comm_init(1, 0, ctx.comm_unique_id())
+            gather_info = QD.time_gather(ctx, batch, cf, cp, world, rank)
+            if world > 1:
+                tg = torch.tensor([gather_info["ms"], gather_info["scan_plus_gather_ms"]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                gather_info["ms"], gather_info["scan_plus_gather_ms"] = float(tg[0].item()), float(tg[1].item())
+            gather_info["rows_per_s_with_gather"] = world * nrows / (gather_info["scan_plus_gather_ms"] * 1e-3)
+        except Exception as exc:      # the exchange is a report beside the bench line, never a reason to lose it
+            gather_info = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # end to end including the result's way back to the host (SURVEY 8d "Timing"): step + D2H of every output column
+    e2e_ms = None
+    if not args.profile_run:
+        try:
+            reps = []
+            for _ in range(3):
+                ctx.synchronize()
+                t1 = time.perf_counter()
+                r = E.filter_project(ctx, batch, cf, cp)
+                r.to_columns()
+                reps.append((time.perf_counter() - t1) * 1e3)
+                r.free()
+            e2e_ms = min(reps)
+        except Exception:
+            e2e_ms = None
 
     if rank == 0:
         kernel_ms = kernel_ms_total / max(1, launches)
         alg_bytes = wl.algorithmic_bytes(nrows, nout)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        try:
-            stream_gbps = ctx.stream_read_bandwidth(min(8 << 30, max(1 << 28, nrows * 8)), 5)
-        except Exception:
-            stream_gbps = None
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-        # WRITE_SIZE, separate passes; profiles/README.md) -- only valid for the workload it was collected on
-        traffic, traffic_src = None, None
+        stream_gbps = None
+        if not args.profile_run:
+            try:
+                stream_gbps = ctx.stream_read_bandwidth(min(8 << 30, max(1 << 28, nrows * 8)), 5)
+            except Exception:
+                stream_gbps = None
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # separate passes; tools/profile_all.sh) -- reported only when it was collected on this workload AND this code
+        key = traffic_key(wl.name, nrows, args.selectivity, args.exec_mode)
+        chash = code_hash(ctx, E, batch, cf, cp, args.exec_mode)
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("workload") == wl.name and tj.get("rows") == nrows and args.exec_mode == "fused":
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+            ent = tj.get("entries", {}).get(key)
+            if ent is not None:
+                if ent.get("code_hash") == chash:
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source")
+                else:
+                    traffic_stale = f"profiles/traffic.json holds {key} for code {ent.get('code_hash')}, this run is {chash}"
         except Exception:
             pass
+        two_pass = args.exec_mode == "fused" and wl.filter is not None and nout >= 0.6 * nrows
         out = {
-            "metric": "rows/sec filter+project over int64/f64 batch (1B rows per GPU); achieved HBM GB/s in roofline",
+            "metric": "rows/sec filter+project over int64/f64 batch; achieved HBM GB/s in roofline",
             "value": world * nrows * args.steps / dt_max,
             "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_median": median(step_ms), "ms_min": min(step_ms) if step_ms else None,
+            "e2e_with_d2h_ms": e2e_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64/f64", "data": "synthetic",
             "config": {"workload": f"{wl.name}: {wl.sql}", "rows_per_gpu": nrows, "rows_total": world * nrows,
                        "selected_rows_total": total_out, "exec_mode": args.exec_mode,
-                       "sharding": "contiguous row ranges by global row index, no data-path collective"},
+                       "sharding": "contiguous row ranges by global row index, no data-path collective",
+                       "rows_rule": "N=1: 1 B rows (BASELINE configs[1]); N>1: 1.25 B rows per GPU (configs[4]: 10 B / 8), same shard at N=2,4"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_stale": traffic_stale, "traffic_key": key, "code_hash": chash,
                          "traffic_gbps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
-                         "kernel": ("qe_fp_count + gb_scan + qe_fp_write (two-pass form, chosen at selectivity >= 0.6)"
-                                    if args.exec_mode == "fused" and wl.filter is not None and nout >= 0.6 * nrows else
+                         # the honest second fraction: bytes the kernel really MOVED (PMC) / kernel time / peak
+                         "frac_moved": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic and kernel_ms > 0 else None,
+                         "kernel": ("qe_fp_count + gb_scan + qe_fp_write (two-pass form, chosen at selectivity >= 0.6)" if two_pass else
                                     "qe_fused" if args.exec_mode == "fused" else "per-node kernels"),
-                         "kernel_ms": kernel_ms,
+                         "kernel_ms": kernel_ms, "kernel_ms_median": median(kern_ms), "kernel_ms_min": min(kern_ms) if kern_ms else None,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes (every input column in full + output rows) / kernel time; "
                                  "the kernel loads later filter / projection columns only for rows still alive (late "
-                                 "materialisation), so measured HBM traffic can be BELOW the algorithmic bytes", "algorithmic_bytes_per_launch": alg_bytes,
+                                 "materialisation), so measured HBM traffic can be BELOW the algorithmic bytes: frac_moved is "
+                                 "the fraction of peak the kernel really sustains", "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_stream_read_gbps": stream_gbps},
         }
         if gather_info is not None:
             out["gather"] = gather_info
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.profile_run:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     batch.free()

@@ -243,11 +243,44 @@ int32_t qe_result_column(const qe_result *result, int32_t col, qe_col_view *out)
 int32_t qe_result_column_to_host(qe_ctx *ctx, const qe_result *result, int32_t col, void *data_out,
                                  uint64_t *validity_out);
 void qe_result_free(qe_ctx *ctx, qe_result *result);
+/* Concatenate results of ONE device, in the given order, into a new result (value columns at row offsets, bitmap
+ * columns shifted into place as 64-row words): what a host does that feeds a table batch by batch and still hands the
+ * reference's single Operator (operator/Operators.kt:5-11) the whole result.  Parts must share schema and dictionaries. */
+int32_t qe_result_concat(qe_ctx *ctx, const qe_result *const *parts, int32_t nparts, qe_result **out);
+
+/* ---- the exchange step of a row-range sharded scan -------------------------------------------------------
+ * One process (one qe_ctx) per GPU; rank r scans rows [r*N/P, (r+1)*N/P) with NO communication.  Only a plan whose root
+ * materialises its result on one rank (evaluator/Planner.kt:30-63: ONE Operator yields the whole result; Main.kt:18
+ * `physicalPlan.map { it }`) exchanges data.  RCCL directly: ncclAllGather of the per-rank result headers, then one
+ * ncclGroupStart/End of ncclRecv (root, at the final offsets) / ncclSend (peers), every peer on its own xGMI link;
+ * rank order = the reference's row order (operator/FilterOperator.kt:17-22 is order preserving).
+ * Bootstrap: rank 0 calls qe_comm_unique_id and hands the 128 bytes to the other ranks through whatever channel the
+ * host has (the JVM host: its own RPC; tests / bench.py: torch.distributed broadcast); then every rank calls
+ * qe_comm_init.  Failures return QE_ERR_COMM. */
+typedef struct { char internal[128]; } qe_comm_id;     /* = ncclUniqueId */
+int32_t qe_comm_unique_id(qe_ctx *ctx, qe_comm_id *out);
+int32_t qe_comm_init(qe_ctx *ctx, int32_t nranks, int32_t rank, const qe_comm_id *id);
+int32_t qe_comm_rank(const qe_ctx *ctx);       /* -1 without a communicator */
+int32_t qe_comm_nranks(const qe_ctx *ctx);     /* 0 without a communicator */
+void qe_comm_destroy(qe_ctx *ctx);             /* also done by qe_ctx_destroy */
+/* Collective.  On `root`, *out = the concatenation of every rank's result in rank order (free with qe_result_free);
+ * on the other ranks *out = NULL.  `local` stays owned by the caller. */
+int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out);
+/* Collective, small control data (aggregate partials, counts): recv gets nranks * nbytes host bytes in rank order.
+ * Aggregations over a sharded table fold the per-GPU partials in rank order on the host. */
+int32_t qe_comm_allgather_host(qe_ctx *ctx, const void *send, size_t nbytes, void *recv);
 
 /* ---- introspection ------------------------------------------------------------------------ */
 /* HIP source the JIT would compile for this plan (NUL terminated, owned by ctx, valid until next call) */
 int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                  const qe_expr *const *projections, int32_t nproj, const char **out);
+/* Which of the fused kernel's two sub-tile geometries this plan runs with on large batches: -1 not decided yet (the first
+ * executions on a batch of >= 32 Mi rows time both, best of 3 each), 0 default, 1 wide.  The decision is persisted next
+ * to the plan's code object in the JIT cache, so a later context / process runs the same geometry without exploring
+ * (*out_from_cache = 1 when it came from there). */
+int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                   const qe_expr *const *projections, int32_t nproj, int32_t *out_chosen,
+                                   int32_t *out_from_cache);
 /* measured device read bandwidth of a plain streaming kernel over nbytes (GB/s): roofline calibration */
 int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, double *out_gbps);
 

@@ -1,0 +1,386 @@
+// qe_comm.cpp -- the ONE exchange step of the path: results of a row-range sharded scan are materialised on
+// one rank.  RCCL is used directly (no PyTorch in the data path): ncclAllGather of the per-rank result headers, then ONE
+// ncclGroupStart/End in which the root posts a ncclRecv per peer and column and every peer a ncclSend per column, so that
+// each peer streams over its OWN xGMI link into the root (a fully connected mesh: a ring would be bound by one link).
+// Value columns land at their final offset (rank order == the reference's row order, FilterOperator.kt:17-22 is order
+// preserving); bitmap columns (BOOLEAN values, validity) travel as raw 64-row WORDS and are funnel-shifted into place on
+// the root (bitmap_place_kernel) -- never expanded to a byte per row.
+//
+// The same placement code concatenates several results of ONE device (qe_result_concat): that is what a host does that
+// feeds a table batch by batch and still hands the reference's single Operator the whole result (Planner.kt:30-63).
+//
+// librccl.so.1 is opened lazily (dlopen) at qe_comm_init, so the library itself loads on hosts without RCCL and shares
+// the RCCL a host process may already have loaded (PyTorch bundles one with the same SONAME).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <numeric>
+
+#include "qe_internal.h"
+#include "qe_kernels.h"
+
+namespace qe {
+
+// ---- the slice of the RCCL API this file uses (rccl.h: ncclResult_t = int, ncclSuccess = 0) ----------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *id) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, qe_comm_id id, int rank) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s) = nullptr;
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclUint8 = 1;   // rccl.h: ncclUint8 = 1
+
+static RcclApi &rccl() {
+    static RcclApi api;
+    if (api.handle) return api;
+    const char *names[] = {std::getenv("QE_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    std::string tried;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+        tried += std::string(tried.empty() ? "" : "; ") + dlerror();
+    }
+    if (!h) fail(QE_ERR_COMM, "RCCL is not available: " + tried);
+    auto sym = [&](const char *name) {
+        void *p = dlsym(h, name);
+        if (!p) fail(QE_ERR_COMM, std::string("librccl lacks ") + name);
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.handle = h;
+    return api;
+}
+
+static void nccl_check(int r, const char *what) {
+    if (r == 0) return;
+    const char *msg = rccl().GetErrorString ? rccl().GetErrorString(r) : "?";
+    fail(QE_ERR_COMM, std::string(what) + " failed: " + (msg ? msg : "?") + " (" + std::to_string(r) + ")");
+}
+#define QE_NCCL(x) ::qe::nccl_check((x), #x)
+
+static size_t width_of(int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 8 : (t == QE_INT32 || t == QE_STRING) ? 4 : 0; }
+static size_t words_of(int64_t n) { return (size_t)((n + 63) / 64); }
+
+// header every rank contributes to the all-gather: its row count and the shape of its result
+struct GatherHeader {
+    int64_t count;
+    int32_t ncols;
+    uint32_t validity_mask;    // bit c: column c carries a validity bitmap on this rank
+    uint64_t type_sig;         // 4 bits per column: the column types must agree on every rank
+};
+
+static GatherHeader header_of(const qe_result *r) {
+    GatherHeader h{};
+    h.count = r->count;
+    h.ncols = (int32_t)r->cols.size();
+    for (size_t c = 0; c < r->cols.size(); c++) {
+        if (r->cols[c].validity) h.validity_mask |= 1u << c;
+        h.type_sig |= (uint64_t)(r->cols[c].type & 15) << (4 * c);
+    }
+    return h;
+}
+
+// The output result of a concatenation / gather: per column a values buffer for `total` rows and, if any part carries a
+// validity bitmap, a validity bitmap (parts without one contribute ones).
+static qe_result *make_output(qe_ctx *ctx, const qe_result *like, int64_t total, uint32_t any_validity) {
+    std::unique_ptr<qe_result> out(new qe_result());
+    out->count = total;
+    out->capacity = total;
+    try {
+        for (size_t c = 0; c < like->cols.size(); c++) {
+            const OutColumn &src = like->cols[c];
+            OutColumn oc;
+            oc.type = src.type;
+            oc.dict = src.dict;
+            oc.dict_handle.d = src.dict;
+            oc.nullable = (any_validity >> c) & 1u;
+            out->cols.push_back(oc);
+            OutColumn &dst = out->cols.back();
+            const size_t nb = src.type == QE_BOOLEAN ? words_of(total) * 8 : width_of(src.type) * (size_t)total;
+            dst.data = ctx->pool.alloc(std::max<size_t>(nb, 16));
+            if (src.type == QE_BOOLEAN && nb) QE_HIP(hipMemsetAsync(dst.data, 0, nb, ctx->stream));
+            if (dst.nullable) {
+                dst.validity = (uint64_t *)ctx->pool.alloc(std::max<size_t>(words_of(total) * 8, 16));
+                if (total > 0) QE_HIP(hipMemsetAsync(dst.validity, 0, words_of(total) * 8, ctx->stream));
+            }
+        }
+    } catch (...) {
+        for (auto &c : out->cols) {
+            ctx->pool.release(c.data);
+            ctx->pool.release(c.validity);
+        }
+        throw;
+    }
+    return out.release();
+}
+
+static void free_output(qe_ctx *ctx, qe_result *r) {
+    if (!r) return;
+    for (auto &c : r->cols) {
+        ctx->pool.release(c.data);
+        ctx->pool.release(c.validity);
+    }
+    delete r;
+}
+
+// scratch buffers that go back to the pool when the call ends
+struct Scratch {
+    qe_ctx *ctx;
+    std::vector<void *> bufs;
+    void *get(size_t bytes) {
+        void *p = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        bufs.push_back(p);
+        return p;
+    }
+    ~Scratch() { for (void *p : bufs) ctx->pool.release(p); }
+};
+
+static uint64_t *ones_bitmap(qe_ctx *ctx, Scratch &sc, int64_t n) {
+    uint64_t *p = (uint64_t *)sc.get(words_of(n) * 8);
+    QE_HIP(hipMemsetAsync(p, 0xff, words_of(n) * 8, ctx->stream));
+    return p;
+}
+
+}  // namespace qe
+
+using namespace qe;
+
+template <typename F>
+static int32_t guarded_comm(qe_ctx *ctx, F &&f) {
+    try {
+        f();
+        return QE_OK;
+    } catch (const Error &e) {
+        if (ctx) ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        if (ctx) ctx->last_error = "host out of memory";
+        return QE_ERR_OOM;
+    } catch (const std::exception &e) {
+        if (ctx) ctx->last_error = e.what();
+        return QE_ERR_INTERNAL;
+    }
+}
+
+static void need_dev(const qe_ctx *ctx) {
+    if (ctx->device < 0) fail(QE_ERR_HIP, "planning-only context (QE_DEVICE_NONE): this call needs a HIP device");
+    QE_HIP(hipSetDevice(ctx->device));
+}
+
+extern "C" {
+
+int32_t qe_comm_unique_id(qe_ctx *ctx, qe_comm_id *out) {
+    if (!ctx || !out) return QE_ERR_INVALID_ARG;
+    return guarded_comm(ctx, [&] { QE_NCCL(rccl().GetUniqueId(out)); });
+}
+
+int32_t qe_comm_init(qe_ctx *ctx, int32_t nranks, int32_t rank, const qe_comm_id *id) {
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return QE_ERR_INVALID_ARG;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        if (ctx->comm) fail(QE_ERR_INVALID_ARG, "qe_comm_init: this context already has a communicator");
+        void *comm = nullptr;
+        QE_NCCL(rccl().CommInitRank(&comm, nranks, *id, rank));
+        ctx->comm = comm;
+        ctx->comm_rank = rank;
+        ctx->comm_nranks = nranks;
+    });
+}
+
+int32_t qe_comm_rank(const qe_ctx *ctx) { return ctx && ctx->comm ? ctx->comm_rank : -1; }
+int32_t qe_comm_nranks(const qe_ctx *ctx) { return ctx && ctx->comm ? ctx->comm_nranks : 0; }
+
+void qe_comm_destroy(qe_ctx *ctx) {
+    if (!ctx || !ctx->comm) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_nranks = 0;
+    ctx->comm_rank = -1;
+}
+
+// every rank contributes nbytes host bytes; recv gets nranks * nbytes in rank order (small control data: aggregate
+// partials, counts).  SURVEY 8f: "Cross-GPU: reduce of the per-GPU partials" -- folded by the host in rank order.
+int32_t qe_comm_allgather_host(qe_ctx *ctx, const void *send, size_t nbytes, void *recv) {
+    if (!ctx || !send || !recv || nbytes == 0) return QE_ERR_INVALID_ARG;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        if (!ctx->comm) fail(QE_ERR_COMM, "qe_comm_allgather_host: no communicator (qe_comm_init)");
+        Scratch sc{ctx, {}};
+        const size_t n = (size_t)ctx->comm_nranks;
+        char *d_send = (char *)sc.get(nbytes), *d_recv = (char *)sc.get(nbytes * n);
+        QE_HIP(hipMemcpyAsync(d_send, send, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        QE_NCCL(rccl().AllGather(d_send, d_recv, nbytes, kNcclUint8, ctx->comm, ctx->stream));
+        QE_HIP(hipMemcpyAsync(recv, d_recv, nbytes * n, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// Concatenate results of ONE device in the given order (values at row offsets, bitmaps shifted into place).
+int32_t qe_result_concat(qe_ctx *ctx, const qe_result *const *parts, int32_t nparts, qe_result **out) {
+    if (!ctx || !out || nparts < 1 || !parts) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        int64_t total = 0;
+        uint32_t any_validity = 0;
+        for (int32_t i = 0; i < nparts; i++) {
+            if (!parts[i]) fail(QE_ERR_INVALID_ARG, "qe_result_concat: null part");
+            const GatherHeader h = header_of(parts[i]), h0 = header_of(parts[0]);
+            if (h.ncols != h0.ncols || h.type_sig != h0.type_sig) fail(QE_ERR_INVALID_ARG, "qe_result_concat: parts differ in schema");
+            if (h.ncols > 16) fail(QE_ERR_UNSUPPORTED, "qe_result_concat: more than 16 columns");
+            for (size_t c = 0; c < parts[i]->cols.size(); c++)
+                if (parts[i]->cols[c].dict != parts[0]->cols[c].dict &&
+                    (!parts[i]->cols[c].dict || !parts[0]->cols[c].dict || parts[i]->cols[c].dict->entries != parts[0]->cols[c].dict->entries))
+                    fail(QE_ERR_INVALID_ARG, "qe_result_concat: STRING columns must share one dictionary");
+            total += h.count;
+            any_validity |= h.validity_mask;
+        }
+        Scratch sc{ctx, {}};
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(make_output(ctx, parts[0], total, any_validity),
+                                                                          [ctx](qe_result *r) { free_output(ctx, r); });
+        int64_t off = 0;
+        for (int32_t i = 0; i < nparts; i++) {
+            const int64_t n = parts[i]->count;
+            if (n == 0) continue;
+            for (size_t c = 0; c < res->cols.size(); c++) {
+                const OutColumn &src = parts[i]->cols[c];
+                OutColumn &dst = res->cols[c];
+                if (src.type == QE_BOOLEAN)
+                    launch_bitmap_place(ctx->stream, (uint64_t *)dst.data, off, (const uint64_t *)src.data, n);
+                else
+                    QE_HIP(hipMemcpyAsync((char *)dst.data + width_of(src.type) * (size_t)off, src.data, width_of(src.type) * (size_t)n,
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+                if (dst.nullable)
+                    launch_bitmap_place(ctx->stream, dst.validity, off, src.validity ? src.validity : ones_bitmap(ctx, sc, n), n);
+            }
+            off += n;
+        }
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        *out = res.release();
+    });
+}
+
+// Materialise a sharded result on rank `root`: *out is the concatenation in rank order there, NULL elsewhere.
+// Collective: every rank of the communicator calls it with its local result (same plan => same column types).
+int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out) {
+    if (!ctx || !local || !out) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        if (!ctx->comm) fail(QE_ERR_COMM, "qe_gather: no communicator (qe_comm_init)");
+        const int nranks = ctx->comm_nranks, rank = ctx->comm_rank;
+        if (root < 0 || root >= nranks) fail(QE_ERR_INVALID_ARG, "qe_gather: root out of range");
+        if (local->cols.size() > 16) fail(QE_ERR_UNSUPPORTED, "qe_gather: more than 16 columns");
+        RcclApi &nc = rccl();
+        Scratch sc{ctx, {}};
+        // (1) all-gather of the result headers (32 B per rank): counts -> offsets, shapes are checked on every rank
+        const GatherHeader mine = header_of(local);
+        std::vector<GatherHeader> hdr((size_t)nranks);
+        {
+            GatherHeader *d_mine = (GatherHeader *)sc.get(sizeof(GatherHeader));
+            GatherHeader *d_all = (GatherHeader *)sc.get(sizeof(GatherHeader) * (size_t)nranks);
+            QE_HIP(hipMemcpyAsync(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+            QE_NCCL(nc.AllGather(d_mine, d_all, sizeof(GatherHeader), kNcclUint8, ctx->comm, ctx->stream));
+            QE_HIP(hipMemcpyAsync(hdr.data(), d_all, sizeof(GatherHeader) * (size_t)nranks, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        int64_t total = 0;
+        uint32_t any_validity = 0;
+        std::vector<int64_t> offset((size_t)nranks, 0);
+        for (int r = 0; r < nranks; r++) {
+            if (hdr[r].ncols != mine.ncols || hdr[r].type_sig != mine.type_sig)
+                fail(QE_ERR_INVALID_ARG, "qe_gather: rank " + std::to_string(r) + " holds a result of a different schema");
+            offset[r] = total;
+            total += hdr[r].count;
+            any_validity |= hdr[r].validity_mask;
+        }
+        const size_t ncols = local->cols.size();
+        const int64_t n_me = mine.count;
+        if (rank != root) {
+            // (2, peer) one grouped send per column buffer: values, then validity words (ones if this shard has none)
+            if (n_me > 0) {
+                std::vector<const uint64_t *> vsend(ncols, nullptr);
+                for (size_t c = 0; c < ncols; c++)
+                    if ((any_validity >> c) & 1u) vsend[c] = local->cols[c].validity ? local->cols[c].validity : ones_bitmap(ctx, sc, n_me);
+                QE_NCCL(nc.GroupStart());
+                for (size_t c = 0; c < ncols; c++) {
+                    const OutColumn &src = local->cols[c];
+                    const size_t nb = src.type == QE_BOOLEAN ? words_of(n_me) * 8 : width_of(src.type) * (size_t)n_me;
+                    QE_NCCL(nc.Send(src.data, nb, kNcclUint8, root, ctx->comm, ctx->stream));
+                    if (vsend[c]) QE_NCCL(nc.Send(vsend[c], words_of(n_me) * 8, kNcclUint8, root, ctx->comm, ctx->stream));
+                }
+                QE_NCCL(nc.GroupEnd());
+            }
+            QE_HIP(hipStreamSynchronize(ctx->stream));   // the local result (and the scratch) may be freed by the caller now
+            return;
+        }
+        // (2, root) receive every peer's values at their final offset; bitmap words into a staging area per (peer, column)
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(make_output(ctx, local, total, any_validity),
+                                                                          [ctx](qe_result *r) { free_output(ctx, r); });
+        struct Staged { uint64_t *words; int64_t off, n; uint64_t *dst; };
+        std::vector<Staged> staged;
+        QE_NCCL(nc.GroupStart());
+        for (int r = 0; r < nranks; r++) {
+            const int64_t n = hdr[r].count;
+            if (n == 0 || r == root) continue;
+            for (size_t c = 0; c < ncols; c++) {
+                OutColumn &dst = res->cols[c];
+                if (dst.type == QE_BOOLEAN) {
+                    uint64_t *st = (uint64_t *)sc.get(words_of(n) * 8);
+                    QE_NCCL(nc.Recv(st, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
+                    staged.push_back({st, offset[r], n, (uint64_t *)dst.data});
+                } else {
+                    QE_NCCL(nc.Recv((char *)dst.data + width_of(dst.type) * (size_t)offset[r], width_of(dst.type) * (size_t)n, kNcclUint8, r,
+                                    ctx->comm, ctx->stream));
+                }
+                if (dst.nullable) {
+                    uint64_t *st = (uint64_t *)sc.get(words_of(n) * 8);
+                    QE_NCCL(nc.Recv(st, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
+                    staged.push_back({st, offset[r], n, dst.validity});
+                }
+            }
+        }
+        QE_NCCL(nc.GroupEnd());
+        // the root's own shard: device-to-device, same placement code as the peers' segments
+        if (n_me > 0) {
+            for (size_t c = 0; c < ncols; c++) {
+                const OutColumn &src = local->cols[c];
+                OutColumn &dst = res->cols[c];
+                if (src.type == QE_BOOLEAN)
+                    launch_bitmap_place(ctx->stream, (uint64_t *)dst.data, offset[root], (const uint64_t *)src.data, n_me);
+                else
+                    QE_HIP(hipMemcpyAsync((char *)dst.data + width_of(src.type) * (size_t)offset[root], src.data,
+                                          width_of(src.type) * (size_t)n_me, hipMemcpyDeviceToDevice, ctx->stream));
+                if (dst.nullable)
+                    launch_bitmap_place(ctx->stream, dst.validity, offset[root], src.validity ? src.validity : ones_bitmap(ctx, sc, n_me), n_me);
+            }
+        }
+        for (const Staged &s : staged) launch_bitmap_place(ctx->stream, s.dst, s.off, s.words, s.n);
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        *out = res.release();
+    });
+}
+
+}  // extern "C"

@@ -52,6 +52,10 @@ const char *fn_name(int fn);
 
 // ---- dictionaries ----------------------------------------------------------------------
 struct DictData {
+    // process-wide serial number, assigned when the dictionary is created: plan caches key on it, never on the
+    // address (an allocator hands a freed dictionary's address to the next one)
+    uint64_t id = next_id();
+    static uint64_t next_id();
     std::vector<std::string> entries;
     std::unordered_map<std::string, int32_t> index;
     int32_t find(const std::string &s) const {
@@ -231,6 +235,10 @@ public:
     // compile (or fetch from memory / disk cache) and load; needs a current device unless load == false
     Kernel get(const std::string &source, const char *entry, bool load = true);
     static std::vector<char> compile(const std::string &source);
+    static std::string source_key(const std::string &source);
+    // persisted measured decisions (geometry choice) next to the code object; -1 = none
+    int load_choice(const std::string &source) const;
+    void store_choice(const std::string &source, int chosen, const std::string &note) const;
     static int scratch_bytes(const std::vector<char> &code);
     int compiles = 0, disk_hits = 0, mem_hits = 0, last_scratch = -1;
 
@@ -289,8 +297,8 @@ struct qe_ctx {
     std::map<std::string, std::shared_ptr<qe::Plan>> plans;
     // geometry choice per fused filter+project plan: the first executions on a large batch time the default geometry and
     // the "wide" one (16 load groups per sub-tile, 512-entry LDS rings, 2 waves per SIMD); the faster one is kept
-    struct GeoChoice { int chosen = -1; int runs[2] = {0, 0}; float best_ms[2] = {1e30f, 1e30f}; };
-    std::map<const qe::Plan *, GeoChoice> geo_choice;
+    struct GeoChoice { int chosen = -1; int runs[2] = {0, 0}; float best_ms[2] = {1e30f, 1e30f}; bool from_cache = false; };
+    std::map<const qe::Plan *, GeoChoice> geo_choice;   // plans live as long as the context: the pointer is never recycled
     std::string source_scratch;
     // profiling of the dominant kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -299,4 +307,7 @@ struct qe_ctx {
     // small persistent device scratch: ticket, total, error (+ pinned host mirror)
     unsigned int *d_ctrl = nullptr;      // [0]=ticket [1]=error, [2..3]=total (u64)
     unsigned long long *h_ctrl = nullptr;// pinned: total, error
+    // RCCL communicator of the exchange step (qe_comm.cpp); null until qe_comm_init
+    void *comm = nullptr;
+    int comm_rank = -1, comm_nranks = 0;
 };

@@ -74,9 +74,48 @@ int Jit::scratch_bytes(const std::vector<char> &code) {
     return -1;
 }
 
-Kernel Jit::get(const std::string &source, const char *entry, bool load) {
+// the compiler is part of a code object's identity: a cache directory that outlives a ROCm update must not serve stale code
+static std::string toolchain_tag() {
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    return std::string(kOptionsTag) + "-rtc" + std::to_string(major) + "." + std::to_string(minor);
+}
+
+static bool looks_like_code_object(const std::vector<char> &code) {
+    return code.size() > 64 && std::memcmp(code.data(), "\x7f" "ELF", 4) == 0;
+}
+
+std::string Jit::source_key(const std::string &source) {
     char key[64];
-    std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source + kOptionsTag), source.size(), kArch);
+    std::snprintf(key, sizeof key, "%016llx_%zu_%s", (unsigned long long)fnv1a(source + toolchain_tag()), source.size(), kArch);
+    return key;
+}
+
+// Measured decisions about a plan (which kernel geometry won) are kept next to its code object, so that a new context /
+// a new process runs the same geometry without exploring again.
+int Jit::load_choice(const std::string &source) const {
+    if (cache_dir_.empty()) return -1;
+    std::ifstream f(cache_dir_ + "/" + source_key(source) + ".geo");
+    int v = -1;
+    if (f && (f >> v) && (v == 0 || v == 1)) return v;
+    return -1;
+}
+
+void Jit::store_choice(const std::string &source, int chosen, const std::string &note) const {
+    if (cache_dir_.empty()) return;
+    ::mkdir(cache_dir_.c_str(), 0777);
+    const std::string path = cache_dir_ + "/" + source_key(source) + ".geo";
+    const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+    std::ofstream f(tmp);
+    if (!f) return;
+    f << chosen << "\n" << note << "\n";
+    f.close();
+    if (f.good()) std::rename(tmp.c_str(), path.c_str());
+    else std::remove(tmp.c_str());
+}
+
+Kernel Jit::get(const std::string &source, const char *entry, bool load) {
+    const std::string key = source_key(source);
     auto it = loaded_.find(key);
     if (it != loaded_.end()) {
         mem_hits++;
@@ -90,30 +129,45 @@ Kernel Jit::get(const std::string &source, const char *entry, bool load) {
         std::ifstream f(path, std::ios::binary);
         if (f) {
             code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            if (!code.empty()) disk_hits++;
+            if (looks_like_code_object(code)) disk_hits++;
+            else code.clear();   // truncated / foreign file: compile again (and overwrite it)
         }
     }
-    if (code.empty()) {
+    bool from_disk = !code.empty();
+    auto compile_and_store = [&]() {
         code = compile(source);
         compiles++;
-        if (!path.empty()) {
-            ::mkdir(cache_dir_.c_str(), 0777);
-            std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
-            std::ofstream f(tmp, std::ios::binary);
-            if (f) {
-                f.write(code.data(), (std::streamsize)code.size());
-                f.close();
-                std::rename(tmp.c_str(), path.c_str());
-                std::ofstream src(path.substr(0, path.size() - 6) + ".hip");
-                if (src) src << source;
-            }
+        from_disk = false;
+        if (path.empty()) return;
+        ::mkdir(cache_dir_.c_str(), 0777);
+        const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return;
+        f.write(code.data(), (std::streamsize)code.size());
+        f.close();
+        if (!f.good()) {   // e.g. ENOSPC: never leave a truncated code object behind
+            std::remove(tmp.c_str());
+            return;
         }
-    }
+        std::rename(tmp.c_str(), path.c_str());
+        std::ofstream src(path.substr(0, path.size() - 6) + ".hip");
+        if (src) src << source;
+    };
+    if (code.empty()) compile_and_store();
     Kernel k;
     k.scratch = scratch_bytes(code);
     last_scratch = k.scratch;
     if (!load) return k;
-    QE_HIP(hipModuleLoadData(&k.module, code.data()));
+    hipError_t le = hipModuleLoadData(&k.module, code.data());
+    if (le != hipSuccess && from_disk) {   // a cached file the runtime rejects: drop it and compile once
+        (void)hipGetLastError();
+        std::remove(path.c_str());
+        compile_and_store();
+        k.scratch = scratch_bytes(code);
+        last_scratch = k.scratch;
+        le = hipModuleLoadData(&k.module, code.data());
+    }
+    QE_HIP(le);
     QE_HIP(hipModuleGetFunction(&k.fn, k.module, entry));
     loaded_[key] = k;
     return k;

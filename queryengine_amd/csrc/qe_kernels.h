@@ -36,4 +36,7 @@ struct GbAggArgs {
 };
 void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a);
 
+// place nbits bits of src at bit offset dst_bit_offset of dst (bitmap words; concatenation of results / gather)
+void launch_bitmap_place(hipStream_t s, uint64_t *dst, int64_t dst_bit_offset, const uint64_t *src, int64_t nbits);
+
 }  // namespace qe

@@ -347,4 +347,38 @@ void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a) {
     hipLaunchKernelGGL(gb_aggregate_kernel, dim3((unsigned)a.slices, (unsigned)a.nparts), dim3(256), lds, s, a);
 }
 
+// ---- bitmap segments (result concatenation / gather) -----------------------------------------------------------------
+// Place `nbits` bits of `src` (bit i = word i>>6, bit i&63) at bit offset `dst_off` of `dst`.  One thread owns one
+// destination word, so the read-modify-write of the two boundary words is race free inside a launch; segments are placed
+// by launches serialised on one stream.  Words: 64 rows each, funnel-shifted -- never expanded to a byte per row.
+__global__ void __launch_bounds__(256) bitmap_place_kernel(u64 *dst, i64 dst_off, const u64 *src, i64 nbits) {
+    const i64 w0 = dst_off >> 6, w1 = (dst_off + nbits - 1) >> 6;
+    const i64 nsrc = (nbits + 63) >> 6;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 w = w0 + (i64)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += stride) {
+        const i64 s = w * 64 - dst_off;          // source bit index of this word's bit 0 (negative in the first word)
+        u64 val;
+        if (s >= 0) {
+            const i64 k = s >> 6;
+            const u32 sh = (u32)(s & 63);
+            val = src[k] >> sh;
+            if (sh != 0 && k + 1 < nsrc) val |= src[k + 1] << (64u - sh);
+        } else {
+            val = src[0] << (u32)(-s);
+        }
+        const i64 lo = s < 0 ? -s : 0;                                   // first bit of this word that belongs to the segment
+        const i64 hi = nbits - s < 64 ? nbits - s : 64;                  // one past its last bit
+        const u64 mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        dst[w] = (dst[w] & ~mask) | (val & mask);
+    }
+}
+
+void launch_bitmap_place(hipStream_t s, uint64_t *dst, int64_t dst_bit_offset, const uint64_t *src, int64_t nbits) {
+    if (nbits <= 0) return;
+    const int64_t words = ((dst_bit_offset + nbits - 1) >> 6) - (dst_bit_offset >> 6) + 1;
+    const int64_t blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(bitmap_place_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, (u64 *)dst,
+                       (i64)dst_bit_offset, (const u64 *)src, (i64)nbits);
+}
+
 }  // namespace qe

@@ -166,7 +166,7 @@ struct Exec {
                           : nd.fn == QE_FN_CMP_GT ? pn::C_GT : nd.fn == QE_FN_CMP_EQ ? pn::C_EQ : pn::C_NE;
             const int ot = e.nodes[nd.ops[0]].type;
             if (ot == QE_DOUBLE) {
-                // (double)int_column OP integral literal, |L| <= 2^53: the conversion is monotone and L is exact, so the
+                // (double)int_column OP integral literal, |L| < 2^53 (strict; see Gen::emit): the conversion is monotone and L is exact, so the
                 // comparison can be done on the integers -- no cast kernel, no 8-byte temporary (same rule as Gen::emit)
                 auto int_child = [&](int id) {
                     const Node &x = e.nodes[id];
@@ -176,7 +176,7 @@ struct Exec {
                 };
                 auto int_lit = [&](int id, int ctype, long long &v) {
                     const Node &x = e.nodes[id];
-                    if (x.kind != N_NUM || x.num != std::floor(x.num) || std::fabs(x.num) > 9007199254740992.0) return false;
+                    if (x.kind != N_NUM || x.num != std::floor(x.num) || std::fabs(x.num) >= 9007199254740992.0) return false;
                     v = (long long)x.num;
                     return ctype == QE_INT64 || (v >= -2147483648ll && v <= 2147483647ll);
                 };
@@ -264,7 +264,7 @@ struct Exec {
                 // unify dictionaries; the codes of a non-literal side stay valid (its dictionary is a prefix)
                 auto ndct = std::make_shared<DictData>();
                 const Vec *base = !t.is_str_lit ? &t : (!f.is_str_lit ? &f : nullptr);
-                if (base) *ndct = *base->dict;
+                if (base) { *ndct = *base->dict; ndct->id = DictData::next_id(); }
                 if (!t.is_str_lit && !f.is_str_lit && t.dict != f.dict) {
                     // union dictionary: THEN side's dictionary is its prefix, the ELSE side's codes are remapped
                     std::vector<int32_t> fmap;

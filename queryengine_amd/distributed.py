@@ -9,7 +9,10 @@ into one batch (RCCL: ncclGroupStart/End around ncclSend/ncclRecv), so that ever
 OWN xGMI link into the root instead of a ring bounded by one link.  Concatenation in rank order
 preserves the reference's output order (FilterOperator.kt:17-22 is order preserving).
 
-The same code runs over gloo with CPU tensors (tests) and over nccl (= RCCL) with GPU tensors.
+The PRODUCT exchange is libqe_hip.so's own (qe_comm_init / qe_gather / qe_comm_allgather_host, RCCL called directly
+from the C ABI -- what a JVM host binds): `comm_init` bootstraps it and `gather_result` / `allreduce_aggregates` use it
+whenever the context holds a communicator.  The torch.distributed forms below (`gatherv`, the gloo branches) restate the
+same offset / order logic for the world-size-2 CPU tests, where no GPU and no RCCL exist.
 """
 from __future__ import annotations
 
@@ -29,6 +32,16 @@ def shard_range(nrows_total: int, rank: int, world: int, align: int = 64) -> Tup
     begin = min(nrows_total, rank * per)
     end = min(nrows_total, begin + per)
     return begin, end
+
+
+def comm_init(ctx, group=None) -> None:
+    """Bootstrap the context's RCCL communicator: rank 0 creates the ncclUniqueId through the C ABI, the host channel
+    that carries its 128 bytes to the other ranks is torch.distributed here (a JVM host uses its own RPC)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.comm_init(world, rank, box[0])
 
 
 def gatherv(tensor, dst: int = 0, group=None):
@@ -106,10 +119,14 @@ def _unpack_bits(words, n: int):
 
 
 def gather_result(result, dst: int = 0, group=None):
-    """Materialise a sharded result on rank `dst`: per output column the values (BOOLEAN: uint8 per
-    row) and, if nullable, a uint8 validity vector, concatenated in rank order.  Returns a list of
-    (values, valid|None) torch tensors on `dst`, None elsewhere."""
+    """Materialise a sharded result on rank `dst`.
+
+    With a communicator on the result's context (comm_init) this is qe_gather: the concatenated `engine.Result` on
+    `dst`, None elsewhere.  Without one (torch.distributed only) it returns, on `dst`, a list of (values, valid|None)
+    torch tensors per output column (BOOLEAN / validity as uint8 per row), None elsewhere."""
     import torch.distributed as dist
+    if result.ctx.comm_nranks > 0:
+        return result.ctx.gather(result, dst)
     from .datatypes import DataType
     out = []
     n = result.count
@@ -199,11 +216,18 @@ def combine_aggregate_partials(partial_fns: Sequence[int], per_rank: Sequence[Se
     return acc
 
 
-def allreduce_aggregates(local: Sequence[Optional[float]], partial_fns: Sequence[int], group=None, device=None):
+def allreduce_aggregates(local: Sequence[Optional[float]], partial_fns: Sequence[int], group=None, device=None, ctx=None):
     """All ranks contribute their partial accumulators ({value, valid} pairs, 16 B per aggregate) with one all-gather and
     fold them in rank order.  MIN/MAX/COUNT are exact; SUM is the sum of the shards' sums (deterministic for a world size)."""
     import torch
     import torch.distributed as dist
+    if ctx is not None and ctx.comm_nranks > 0:       # the C ABI's own all-gather (RCCL), no torch in the path
+        payload = np.array([[0.0 if v is None else float(v), 0.0 if v is None else 1.0] for v in local], dtype=np.float64)
+        per_rank = []
+        for blob in ctx.allgather_host(payload.tobytes()):
+            h = np.frombuffer(blob, dtype=np.float64).reshape(-1, 2)
+            per_rank.append([float(h[j, 0]) if h[j, 1] != 0.0 else None for j in range(h.shape[0])])
+        return combine_aggregate_partials(partial_fns, per_rank)
     world = dist.get_world_size(group)
     mine = torch.tensor([[0.0 if v is None else float(v), 0.0 if v is None else 1.0] for v in local],
                         dtype=torch.float64, device=device).reshape(-1, 2)
@@ -223,7 +247,7 @@ def sharded_filter_aggregate(ctx, batch, cf, exprs, aggs: Sequence[int], group=N
     from . import engine as E
     fns, src, recipe = expand_partial_aggregates(aggs)
     local, _ = E.filter_aggregate(ctx, batch, cf, [exprs[i] for i in src], fns)
-    merged = allreduce_aggregates(local, fns, group, device=torch.device("cuda", ctx.device))
+    merged = allreduce_aggregates(local, fns, group, device=torch.device("cuda", ctx.device), ctx=ctx)
     return finish_partials(aggs, recipe, merged)
 
 
@@ -285,30 +309,49 @@ def sharded_filter_groupby(ctx, batch, cf, keys, exprs, aggs: Sequence[int], gro
 
 
 def time_gather(ctx, batch, cf, cp, world: int, rank: int, reps: int = 3):
-    """bench.py --gather: time the materialising exchange separately from the scan."""
+    """bench.py: time the materialising exchange (qe_gather through the C ABI) separately from the scan, and the scan +
+    gather back to back ("for cfg 5 with and without the RCCL gather")."""
     import torch
     import torch.distributed as dist
     from . import engine as E
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
     res = E.filter_project(ctx, batch, cf, cp)
-    best = None
-    total = 0
+    best, best_both = None, None
+    rows_on_root, nbytes = 0, 0
     for _ in range(reps):
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
-        cols = gather_result(res, 0) if world > 1 else [result_column_tensor(res, c) for c in range(res.ncols)]
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        g = ctx.gather(res, 0)
+        barrier()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-        if rank == 0 and cols:
-            total = int(cols[0][0].shape[0])
-    nbytes = 0
-    if rank == 0:
-        nbytes = sum(int(c[0].numel()) * c[0].element_size() for c in cols)
+        if g is not None:
+            rows_on_root = g.count
+            nbytes = 0
+            for c in range(g.ncols):
+                v = g.view(c)
+                nbytes += (g.count + 63) // 64 * 8 if v.type == 2 else g.count * (8 if v.type in (1, 3) else 4)
+                if v.validity:
+                    nbytes += (g.count + 63) // 64 * 8
+            g.free()
     res.free()
-    return {"ms": best * 1e3, "rows_on_root": total, "bytes_on_root": nbytes,
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        r = E.filter_project(ctx, batch, cf, cp)
+        g = ctx.gather(r, 0)
+        barrier()
+        dt = time.perf_counter() - t0
+        best_both = dt if best_both is None else min(best_both, dt)
+        if g is not None:
+            g.free()
+        r.free()
+    return {"ms": best * 1e3, "scan_plus_gather_ms": best_both * 1e3, "rows_on_root": rows_on_root, "bytes_on_root": nbytes,
             "gbps_into_root": (nbytes / best / 1e9) if best else None,
-            "method": "count all-gather + grouped ncclSend/ncclRecv (direct peer links), rank order"}
+            "method": "qe_gather (C ABI, RCCL direct): ncclAllGather of result headers + one ncclGroupStart/End of "
+                      "ncclRecv at final offsets / ncclSend per column (direct peer links), rank order, bitmap words"}

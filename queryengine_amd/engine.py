@@ -92,6 +92,49 @@ class Context:
         N.check(self.handle, self._lib.qe_stream_read_write_time(self.handle, nbytes, write_every, reps, C.byref(ms), C.byref(wb)))
         return ms.value, wb.value
 
+    # ---- the exchange step of a sharded scan (qe_comm_* / qe_gather) ----
+    def comm_unique_id(self) -> bytes:
+        """ncclUniqueId created by this rank (rank 0 hands it to the others through the host's own channel)."""
+        buf = C.create_string_buffer(N.COMM_ID_BYTES)
+        N.check(self.handle, self._lib.qe_comm_unique_id(self.handle, buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        assert len(unique_id) == N.COMM_ID_BYTES
+        buf = C.create_string_buffer(unique_id, N.COMM_ID_BYTES)
+        N.check(self.handle, self._lib.qe_comm_init(self.handle, nranks, rank, buf))
+
+    @property
+    def comm_rank(self) -> int:
+        return int(self._lib.qe_comm_rank(self.handle))
+
+    @property
+    def comm_nranks(self) -> int:
+        return int(self._lib.qe_comm_nranks(self.handle))
+
+    def comm_destroy(self) -> None:
+        self._lib.qe_comm_destroy(self.handle)
+
+    def gather(self, result: "Result", root: int = 0) -> Optional["Result"]:
+        """qe_gather (collective): the concatenation of every rank's result in rank order on `root`, None elsewhere."""
+        h = C.c_void_p()
+        N.check(self.handle, self._lib.qe_gather(self.handle, result.handle, root, C.byref(h)))
+        return Result(self, h) if h.value else None
+
+    def allgather_host(self, payload: bytes) -> List[bytes]:
+        """qe_comm_allgather_host (collective): every rank's `payload` (equal sizes), in rank order."""
+        n = self.comm_nranks
+        recv = C.create_string_buffer(len(payload) * n)
+        N.check(self.handle, self._lib.qe_comm_allgather_host(self.handle, payload, len(payload), recv))
+        return [recv.raw[i * len(payload):(i + 1) * len(payload)] for i in range(n)]
+
+    def concat(self, parts: Sequence["Result"]) -> "Result":
+        """qe_result_concat: results of this device, concatenated in the given order."""
+        arr = (C.c_void_p * max(1, len(parts)))(*[p.handle for p in parts])
+        h = C.c_void_p()
+        N.check(self.handle, self._lib.qe_result_concat(self.handle, arr, len(parts), C.byref(h)))
+        return Result(self, h)
+
     def dictionary(self, entries: Sequence[str]) -> "Dictionary":
         key = tuple(entries)
         d = self._dicts.get(key)
@@ -307,6 +350,16 @@ def prepare(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpressio
             projections: Sequence[CompiledExpression]) -> None:
     N.check(ctx.handle, ctx._lib.qe_filter_project_prepare(ctx.handle, batch.handle, filter.handle if filter else None,
                                                            _expr_array(projections), len(projections)))
+
+
+def chosen_geometry(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                    projections: Sequence[CompiledExpression]):
+    """qe_filter_project_geometry: (chosen: -1 undecided / 0 default / 1 wide, came from the JIT cache?)."""
+    chosen, cached = C.c_int32(), C.c_int32()
+    N.check(ctx.handle, ctx._lib.qe_filter_project_geometry(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                            _expr_array(projections), len(projections), C.byref(chosen),
+                                                            C.byref(cached)))
+    return int(chosen.value), bool(cached.value)
 
 
 def generated_source(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],

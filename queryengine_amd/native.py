@@ -26,6 +26,7 @@ EXEC_FUSED, EXEC_PER_NODE = 0, 1
 CMP_TOTAL_ORDER, CMP_IEEE = 0, 1
 GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE, GEN_DICT_MOD, GEN_I64_ROWID = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_COUNT, AGG_AVG = range(5)
+COMM_ID_BYTES = 128
 
 
 class QeError(RuntimeError):
@@ -96,7 +97,16 @@ SYMBOLS = [
     ("qe_result_column", C.c_int32, [_P, C.c_int32, C.POINTER(ColView)]),
     ("qe_result_column_to_host", C.c_int32, [_P, _P, C.c_int32, _P, _P]),
     ("qe_result_free", None, [_P, _P]),
+    ("qe_result_concat", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(_P)]),
+    ("qe_comm_unique_id", C.c_int32, [_P, _P]),
+    ("qe_comm_init", C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
+    ("qe_comm_rank", C.c_int32, [_P]),
+    ("qe_comm_nranks", C.c_int32, [_P]),
+    ("qe_comm_destroy", None, [_P]),
+    ("qe_gather", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
+    ("qe_comm_allgather_host", C.c_int32, [_P, _P, C.c_size_t, _P]),
     ("qe_filter_project_source", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_char_p)]),
+    ("qe_filter_project_geometry", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("qe_stream_read_bandwidth", C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     ("qe_stream_read_write_time", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]

@@ -136,9 +136,13 @@ class ColumnarScanOperator(Operator):
     def device_batch(self, ctx: E.Context) -> E.DeviceBatch:
         """Pin the projected columns to HBM once per context; later opens reuse the batch."""
         cache = self.table.__dict__.setdefault("_device_batches", {})
+        # batches of contexts that were closed meanwhile are dropped (their handles died with the context)
+        for k in [k for k, v in cache.items() if v.ctx.handle is None or v.handle is None]:
+            del cache[k]
         key = (id(ctx), tuple(self.projection))
         b = cache.get(key)
-        if b is None or b.handle is None or ctx.handle is None:
+        # id() values are recycled after a Context is collected: a hit only counts if the batch belongs to THIS context
+        if b is None or b.ctx is not ctx or b.handle is None or ctx.handle is None:
             b = E.DeviceBatch.from_columns(ctx, self._columns)
             cache[key] = b
         return b

@@ -67,7 +67,11 @@ def assert_columns_equal(got: Column, want: Column, what: str = "") -> None:
 
 SPECIAL_F64 = [0.0, -0.0, 1.0, -1.0, 0.5, 2.5, 100.0, -7.5, 7.5, float("inf"), float("-inf"), float("nan"),
                5e-324, -5e-324, 1.7976931348623157e308, 2.0 ** 53, -(2.0 ** 53), 1e-300, 3.0, 99.99999999999999]
-SPECIAL_I64 = [0, 1, -1, 2, -2, 100, 99, 101, 2 ** 31, -(2 ** 31), 2 ** 53, -(2 ** 53), 2 ** 63 - 1, -(2 ** 63), 7, -7]
+SPECIAL_I64 = [0, 1, -1, 2, -2, 100, 99, 101, 2 ** 31, -(2 ** 31), 2 ** 53, -(2 ** 53), 2 ** 63 - 1, -(2 ** 63), 7, -7,
+               2 ** 53 + 1, -(2 ** 53 + 1), 2 ** 53 + 2, -(2 ** 53 + 2), 2 ** 53 - 1, -(2 ** 53 - 1)]
+# literals around the exact-integer limit of a double: (double)int64 OP literal must behave like the widened compare
+# (BytecodeCompiler.kt:298-320), also where 2^53 and 2^53+1 collapse onto the same double
+BOUNDARY_LITERALS = [2.0 ** 53, -(2.0 ** 53), 2.0 ** 53 - 1, -(2.0 ** 53 - 1), 2.0 ** 53 + 2, 2.0 ** 63, -(2.0 ** 63)]
 SPECIAL_I32 = [0, 1, -1, 2, -2, 100, 99, 101, 2 ** 31 - 1, -(2 ** 31), 7, -7, 8766, 9131]
 
 
@@ -118,7 +122,7 @@ class ExprGen:
         if depth <= 0 or r.random() < 0.25:
             if leaves and r.random() < 0.75:
                 return r.choice(leaves)
-            return num(r.choice([0.0, 1.0, 2.0, 10.0, 100.0, 0.5, -3.0, 1e9, 7.0]))
+            return num(r.choice([0.0, 1.0, 2.0, 10.0, 100.0, 0.5, -3.0, 1e9, 7.0, 99.5] + BOUNDARY_LITERALS))
         k = r.random()
         if k < 0.1:
             return fn(Fn.UNARY_MINUS, self.numeric(depth - 1))

@@ -146,6 +146,28 @@ def test_integer_extension_wrap_div_mod(any_ctx, oracle):
     run_both(any_ctx, oracle, cols, None, projs)
 
 
+def test_int64_compare_against_literals_at_the_2_53_boundary(any_ctx, oracle):
+    """(double)int64 OP literal is the widened comparison (BytecodeCompiler.kt:298-320: Double.compare on the converted
+    value).  At L = +-2^53 the integers 2^53 and 2^53+1 convert to the same double, so comparing on the integers there is
+    wrong (round-1 bug in both executors); every literal of the pool, all six comparisons, both operand orders."""
+    from helpers import BOUNDARY_LITERALS
+    vals = [2 ** 53, -(2 ** 53), 2 ** 53 + 1, -(2 ** 53 + 1), 2 ** 53 + 2, -(2 ** 53 + 2), 2 ** 53 - 1, -(2 ** 53 - 1),
+            2 ** 53 + 3, 2 ** 63 - 1, -(2 ** 63), 2 ** 63 - 512, 2 ** 63 - 513, 0, 1, -1]
+    x = Column(I64, np.array(vals * 9, dtype=np.int64))
+    x32 = Column(I32, np.array(([2 ** 31 - 1, -(2 ** 31), 0, 1, -1, 7, 100, -100] * 18), dtype=np.int32))
+    X, Y = col("x", 0, I64), col("y", 1, I32)
+    cmps = (Fn.CMP_LT, Fn.CMP_LE, Fn.CMP_GE, Fn.CMP_GT, Fn.CMP_EQ, Fn.CMP_NE)
+    for lit in BOUNDARY_LITERALS + [2.0 ** 31, -(2.0 ** 31), 2.0 ** 31 - 1]:
+        projs = [fn(f, X, num(lit)) for f in cmps] + [fn(f, num(lit), X) for f in cmps]
+        projs += [fn(Fn.CMP_LE, Y, num(lit)), fn(Fn.CMP_EQ, num(lit), Y)]
+        got = run_both(any_ctx, oracle, [x, x32], None, projs)
+        if lit == 2.0 ** 53:   # the case the integer shortcut got wrong: (double)(2^53+1) == 2^53
+            assert got[4].to_list()[2] is True and got[3].to_list()[2] is False
+        # as a Filter too (the fused kernel's conjunct path)
+        run_both(any_ctx, oracle, [x, x32], fn(Fn.CMP_LE, X, num(lit)), [X])
+        run_both(any_ctx, oracle, [x, x32], fn(Fn.AND, fn(Fn.CMP_GT, X, num(lit)), fn(Fn.CMP_GE, Y, num(0))), [X, Y])
+
+
 def test_integers_within_2_53_match_double_only_reference(any_ctx, oracle):
     """with |values| <= 2^53 the INT64 extension equals the DOUBLE-only reference."""
     rng = np.random.default_rng(11)
@@ -306,6 +328,46 @@ def test_full_size_1b_rows_properties(gpu_ctx, oracle):
     gpu_ctx.trim()
 
 
+@pytest.mark.parametrize("name", ["config3", "config4", "config4_10keys"])
+def test_full_size_bench_workloads_properties(gpu_ctx, oracle, name):
+    """BASELINE configs 3 and 4 at their FULL size, through the very workload objects bench.py runs (W.config3() /
+    W.config4(): same generator specs, same filter, same projections -- not look-alikes) plus one appended row-id column:
+    projected global row ids strictly increasing (order kept, nothing duplicated), count == an independent aggregate
+    COUNT, the expected selectivity, two far-apart windows walked row by row by the oracle, and a second run identical."""
+    from queryengine_amd import workloads as W
+    wl = {"config3": W.config3, "config4": W.config4, "config4_10keys": lambda: W.config4(nkeys=10, key="k0004")}[name]()
+    n = wl.default_rows
+    specs = [c.spec(gpu_ctx) for c in wl.columns]
+    rid_spec = N.GenSpec(); rid_spec.kind = N.GEN_I64_ROWID; rid_spec.col_id = 99
+    batch = E.DeviceBatch.generate(gpu_ctx, specs + [rid_spec], n)
+    R_ = col("rowid", len(wl.columns), I64)
+    proj_exprs = list(wl.projections) + [R_]
+    cf = gpu_ctx.compile(wl.filter)
+    cp = [gpu_ctx.compile(p) for p in proj_exprs]
+    r1 = E.filter_project(gpu_ctx, batch, cf, cp)
+    cols1 = r1.to_columns()
+    rid = cols1[-1].data
+    assert abs(r1.count / n - wl.expected_selectivity) < 0.02 * wl.expected_selectivity + 1e-5
+    assert np.all(np.diff(rid) > 0) and rid[0] >= 0 and rid[-1] < n
+    vals, nsel = E.filter_aggregate(gpu_ctx, batch, cf, [gpu_ctx.compile(R_)], [N.AGG_COUNT])
+    assert nsel == r1.count == int(vals[0])
+    dicts = [getattr(c, "dictionary", None) for c in wl.columns] + [None]
+    for begin in (0, (n - 700_000) - (n - 700_000) % 64):
+        m = 600_000
+        win = [batch.column_to_host(j, begin, m, dictionary=dicts[j]) for j in range(len(dicts))]
+        want = oracle.filter_project(win, wl.filter, proj_exprs, oracle.BYTECODE_COMPILER)
+        lo = int(np.searchsorted(rid, begin))
+        k = len(want[0])
+        assert k > 0 and np.array_equal(rid[lo:lo + k], want[-1].data)
+        assert lo + k == len(rid) or rid[lo + k] >= begin + m
+        for g, w in zip(cols1[:-1], want[:-1]):
+            assert_columns_equal(Column(g.type, g.data[lo:lo + k], None, g.dictionary), w, f"{name} window at {begin}")
+    r2 = E.filter_project(gpu_ctx, batch, cf, cp)
+    assert r2.count == r1.count and np.array_equal(r2.column_to_host(len(cp) - 1).data, rid)
+    r1.free(); r2.free(); batch.free()
+    gpu_ctx.trim()
+
+
 def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
     """The fused executor remembers the selectivity a plan showed: the first execution is single-pass, the next one of a
     high-selectivity plan runs count -> scan -> direct write.  Both give the reference's rows in input order."""
@@ -429,14 +491,32 @@ def test_wide_geometry_parity(oracle):
     ctx.close()
 
 
-def test_geometry_choice_on_a_large_batch(oracle):
-    """From 32 Mi rows on, the first two executions of a plan time the two geometries and the faster one is kept: every
-    execution -- exploring or settled -- returns exactly the oracle's rows."""
+def test_geometry_choice_on_a_large_batch(oracle, tmp_path):
+    """From 32 Mi rows on, the first executions of a plan time the two geometries (best of 3 each) and the faster one is
+    kept: every execution -- exploring or settled -- returns exactly the oracle's rows.  The decision is persisted next to
+    the code object: a NEW context on the same JIT cache runs the same geometry without exploring (same plan => same
+    geometry)."""
     from queryengine_amd import workloads as W
     n = 34_000_001
-    ctx = E.Context(device=0)
-    _workload_vs_oracle(ctx, oracle, W.config2(n), n, reps=4)
+    cache = str(tmp_path / "jit")
+    ctx = E.Context(device=0, jit_cache_dir=cache)
+    wl = W.config2(n)
+    batch = E.DeviceBatch.describe(ctx, [Column(c.type, np.zeros(2, dtype=np.int64 if c.type == I64 else np.float64)) for c in wl.columns])
+    cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
+    assert E.chosen_geometry(ctx, batch, cf, cp) == (-1, False)
+    _workload_vs_oracle(ctx, oracle, wl, n, reps=5)
+    assert E.chosen_geometry(ctx, batch, cf, cp)[0] == -1          # 5 of the 6 exploring executions
+    _workload_vs_oracle(ctx, oracle, wl, n, reps=2)
+    chosen, cached = E.chosen_geometry(ctx, batch, cf, cp)
+    assert chosen in (0, 1) and not cached
     plain = W.config2(n)
     plain.filter = None                                   # a projection without a Filter takes part in the choice too
     _workload_vs_oracle(ctx, oracle, plain, n, reps=3)
     ctx.close()
+    ctx2 = E.Context(device=0, jit_cache_dir=cache)
+    batch2 = E.DeviceBatch.describe(ctx2, [Column(c.type, np.zeros(2, dtype=np.int64 if c.type == I64 else np.float64)) for c in wl.columns])
+    cf2, cp2 = ctx2.compile(wl.filter), [ctx2.compile(p) for p in wl.projections]
+    assert E.chosen_geometry(ctx2, batch2, cf2, cp2) == (chosen, True)
+    _workload_vs_oracle(ctx2, oracle, wl, n, reps=1)       # runs the persisted geometry at once
+    assert E.chosen_geometry(ctx2, batch2, cf2, cp2) == (chosen, True)
+    ctx2.close()

@@ -268,3 +268,54 @@ def test_late_materialisation_splits_the_filter_into_conjunct_stages(native_lib,
         assert ("if (keep[u][0] || keep[u][1]) {" in src) == staged
         assert "qe_fp_count" in src and "qe_fp_write" in src       # the two-pass form lives in the same module
         ctx.close()
+
+
+def test_plan_cache_keys_on_dictionary_identity_not_address(native_lib, tmp_path):
+    """A C-ABI caller frees a batch and its dictionary, then creates a new dictionary: the allocator hands back the same
+    address.  The fused-plan cache must not mistake it for the old one (round-1 bug: `s = 'b'` compiled to the OLD
+    dictionary's code in half of the iterations).  Planning-only context, raw C ABI (the Python layer would keep every
+    dictionary alive and hide it)."""
+    import ctypes as C
+    L = native_lib
+    ctx = E.Context(device=None, jit_cache_dir=str(tmp_path))
+    s_eq_b = ctx.compile(FunctionExpression(Fn.CMP_EQ, [ColumnExpression("s", 0, S), StringLiteralExpression("b")], B))
+    proj = ctx.compile(ColumnExpression("s", 0, S))
+    seen = set()
+    for it in range(60):
+        entries = [b"a", b"b"] if it % 2 == 0 else [b"b", b"a"]
+        arr = (C.c_char_p * 2)(*entries)
+        d = C.c_void_p()
+        N.check(ctx.handle, L.qe_dict_create(ctx.handle, 2, arr, C.byref(d)))
+        seen.add(d.value)
+        desc = (N.ColDesc * 1)()
+        desc[0].type = int(S)
+        desc[0].dict = d
+        bh = C.c_void_p()
+        N.check(ctx.handle, L.qe_batch_describe(ctx.handle, 128, 1, desc, C.byref(bh)))
+        out = C.c_char_p()
+        projs = (C.c_void_p * 1)(proj.handle)
+        N.check(ctx.handle, L.qe_filter_project_source(ctx.handle, bh, s_eq_b.handle, projs, 1, C.byref(out)))
+        src = out.value.decode()
+        want = 1 if it % 2 == 0 else 0
+        assert f"(c0 == {want})" in src, f"iteration {it}: literal 'b' must compile to code {want}"
+        L.qe_batch_free(ctx.handle, bh)
+        L.qe_dict_free(ctx.handle, d)
+    ctx.close()
+
+
+def test_int_compare_shortcut_stops_below_2_53(plan_ctx):
+    """Generated source: (double)int64_col OP integral literal is compared on the integers only for |L| < 2^53; at
+    L = +-2^53 (where 2^53 and 2^53+1 convert to the same double) the widened compare stays."""
+    x = Column(I64, np.zeros(4, dtype=np.int64))
+    batch = E.DeviceBatch.describe(plan_ctx, [x])
+    X = ColumnExpression("x", 0, I64)
+
+    def src(lit):
+        return E.generated_source(plan_ctx, batch, plan_ctx.compile(FunctionExpression(Fn.CMP_LE, [X, NumericLiteralExpression(lit)])),
+                                  [plan_ctx.compile(X)])
+    assert "(c0 <= 9007199254740991ll)" in src(2.0 ** 53 - 1)
+    assert "(c0 <= -9007199254740991ll)" in src(-(2.0 ** 53 - 1))
+    for lit in (2.0 ** 53, -(2.0 ** 53), 2.0 ** 60):
+        text = src(lit)
+        assert "ll)" not in text.split("qe_conj0")[1].split("}")[0], lit     # no integer literal compare in the conjunct
+        assert "((double)c0)" in text

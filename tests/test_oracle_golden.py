@@ -78,6 +78,27 @@ def test_self_derived_compare_table(oracle):
             assert oracle.eval_row(e, [x, y], oracle.CLOSURE_COMPILER) == row["ieee"][name], (row, name, "closure")
 
 
+def test_self_derived_int64_widening_at_2_53(oracle):
+    """Self-derived (JLS 5.1.2 long -> double rounds to nearest even; BytecodeCompiler.kt:298-320 compares the widened
+    values): 2^53 + 1 converts to 2^53, so `x <= 2^53` and `x == 2^53` are TRUE for x = 2^53 + 1 and `x > 2^53` FALSE --
+    the answers an integer comparison would get wrong.  Not held by the reference's tests: parity unpinned."""
+    I64 = DataType.INT64
+    x = Column(I64, np.array([2 ** 53 + 1, 2 ** 53 + 2, 2 ** 53, -(2 ** 53) - 1, 2 ** 63 - 1], dtype=np.int64))
+    X = ColumnExpression("x", 0, I64)
+    L = NumericLiteralExpression(2.0 ** 53)
+    projs = [FunctionExpression(f, [X, L], DataType.BOOLEAN) for f in (Function.CMP_LE, Function.CMP_EQ, Function.CMP_GT, Function.CMP_NE)]
+    projs.append(FunctionExpression(Function.CMP_GE, [X, NumericLiteralExpression(-(2.0 ** 53))], DataType.BOOLEAN))
+    projs.append(FunctionExpression(Function.CMP_LT, [X, NumericLiteralExpression(2.0 ** 63)], DataType.BOOLEAN))
+    for mode in MODES:
+        le, eq, gt, ne, ge_neg, lt63 = (c.to_list() for c in oracle.filter_project([x], None, projs, mode))
+        assert le == [True, False, True, True, False]
+        assert eq == [True, False, True, False, False]
+        assert gt == [False, True, False, False, True]
+        assert ne == [False, True, False, True, True]
+        assert ge_neg == [True, True, True, True, True]       # (double)(-2^53 - 1) == -2^53
+        assert lt63 == [True, True, True, True, False]        # (double)(2^63 - 1) == 2^63
+
+
 def test_self_derived_mod_and_fma(oracle):
     D = DataType.DOUBLE
     a, b = ColumnExpression("a", 0, D), ColumnExpression("b", 1, D)
