@@ -127,9 +127,11 @@ def traffic_key(workload: str, rows: int, selectivity, exec_mode: str) -> str:
 
 def code_hash(ctx, E, batch, cf, cp, exec_mode: str) -> str:
     """Identity of the code a traffic measurement belongs to: the generated kernel source (fused) or the per-node sources."""
-    if exec_mode == "fused":
-        return hashlib.sha1(E.generated_source(ctx, batch, cf, cp).encode()).hexdigest()[:16]
     h = hashlib.sha1()
+    if exec_mode == "fused":   # the plan's generated source + the generator itself (the dense / two-pass forms come from it too)
+        h.update(E.generated_source(ctx, batch, cf, cp).encode())
+        h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", "qe_codegen.cpp"), "rb").read())
+        return h.hexdigest()[:16]
     for f in ("qe_pernode.cpp", "qe_pernode_kernels.hip"):
         h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
@@ -302,7 +304,7 @@ def main():
                     traffic_stale = f"profiles/traffic.json holds {key} for code {ent.get('code_hash')}, this run is {chash}"
         except Exception:
             pass
-        two_pass = args.exec_mode == "fused" and wl.filter is not None and nout >= 0.6 * nrows
+        dense = args.exec_mode == "fused" and wl.filter is not None and nout >= 0.12 * nrows
         out = {
             "metric": "rows/sec filter+project over int64/f64 batch; achieved HBM GB/s in roofline",
             "value": world * nrows * args.steps / dt_max,
@@ -323,8 +325,8 @@ def main():
                          "traffic_gbps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
                          # the honest second fraction: bytes the kernel really MOVED (PMC) / kernel time / peak
                          "frac_moved": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic and kernel_ms > 0 else None,
-                         "kernel": ("qe_fp_count + gb_scan + qe_fp_write (two-pass form, chosen at selectivity >= 0.6)" if two_pass else
-                                    "qe_fused" if args.exec_mode == "fused" else "per-node kernels"),
+                         "kernel": ("qe_fused (dense single-pass form, chosen from selectivity 0.12 on)" if dense else
+                                    "qe_fused (LDS-ring single-pass form)" if args.exec_mode == "fused" else "per-node kernels"),
                          "kernel_ms": kernel_ms, "kernel_ms_median": median(kern_ms), "kernel_ms_min": min(kern_ms) if kern_ms else None,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes (every input column in full + output rows) / kernel time; "
                                  "the kernel loads later filter / projection columns only for rows still alive (late "

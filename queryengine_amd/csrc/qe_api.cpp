@@ -222,6 +222,7 @@ int32_t qe_ctx_reset_kernel_time(qe_ctx *ctx) {
     ctx->launches = 0;
     return QE_OK;
 }
+int32_t qe_ctx_last_form(const qe_ctx *ctx) { return ctx ? ctx->last_form : -1; }
 int32_t qe_ctx_synchronize(qe_ctx *ctx) {
     if (!ctx) return QE_ERR_INVALID_ARG;
     return guarded(ctx, [&] { need_device(ctx); QE_HIP(hipStreamSynchronize(ctx->stream)); });
@@ -495,6 +496,10 @@ int32_t qe_stream_read_write_time(qe_ctx *ctx, int64_t nbytes, int32_t write_eve
 // ---- plans --------------------------------------------------------------------------------------------
 namespace {
 
+// a plan that kept at least this share of its rows last time runs the dense single-pass kernel next time (measured
+// crossover against the LDS-ring kernel on cfg 2, 1 B rows: 10 % 4.14 vs 4.23 ms, 25 % 5.7 vs 4.5 ms)
+constexpr double kDenseFromSelectivity = 0.12;
+
 FusedGeometry geometry_of(const qe_ctx *ctx) {
     FusedGeometry g;
     const int t = ctx->opts.tuning[0], u = ctx->opts.tuning[1];
@@ -523,7 +528,7 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
 
 std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load,
-                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false) {
+                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false, bool dense = false) {
     if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
     CodegenInput in;
     in.filter = filter ? &filter->e : nullptr;
@@ -550,9 +555,20 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
     in.debug_mask = ctx->opts.tuning[5] & 255;   // bits 256.. are host-side switches, not ablation builds
     in.staged = (ctx->opts.tuning[5] & 2048) == 0;
+    in.dense = dense && filter != nullptr && !agg_fns;
+    if (in.dense) {   // the dense kernel has its own shape: a workgroup per tile of QE_WAVES sub-tiles, one tile parked in LDS
+        in.geo.subs_per_chunk = 1;
+        in.geo.stagger = 0;
+        // measured on cfg 2, 1 B rows (tools/sel_sweep.py): 4 waves x 1024 rows = 4 Ki-row tiles (244 K tickets, 64 KiB of LDS
+        // for 16-byte rows, two workgroups per CU) ran 4.0 - 6.4 ms from 1 % to 100 %; 2 Ki-row tiles are bound by the
+        // single-address ticket rate (~77 tickets/us: 6.3 ms whatever the selectivity), 8 / 16 Ki-row tiles leave one
+        // workgroup per CU (5 - 15 % slower)
+        if (ctx->opts.tuning[0] == 0) in.geo.threads = 256;
+        if (ctx->opts.tuning[1] == 0) in.geo.unroll = 8;
+    }
     in.filter_load_stages = (ctx->opts.tuning[5] & 4096) ? 1 : 0;   // bit 4096: every filter column in the first load stage   // bit 2048: load every column for every row (no late materialisation)
     std::ostringstream key;
-    key << "m" << (agg_fns ? 1 : 0) << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
+    key << "m" << (agg_fns ? 1 : 0) << (in.dense ? "D" : "") << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
         << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
@@ -575,7 +591,22 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
     auto plan = std::make_shared<Plan>();
     plan->cg = generate_fused_source(in);
-    if (!agg_fns && in.filter) {
+    if (in.dense) {
+        // LDS budget of the parked tile: (waves * 128 * U) rows of every output column.  64 KiB lets two workgroups share a
+        // CU (the second one streams while the first waits at its barriers); shrink the sub-tile, then the workgroup.
+        size_t rowbytes = 0;
+        for (const OutSpec &o : plan->cg.outs)
+            rowbytes += (o.type == QE_BOOLEAN ? 1 : (o.type == QE_DOUBLE || o.type == QE_INT64) ? 8 : 4) + (o.nullable ? 1 : 0);
+        rowbytes = std::max<size_t>(rowbytes, 1);
+        auto tile_bytes = [&]() { return (size_t)(in.geo.threads / 64) * 128 * in.geo.unroll * rowbytes; };
+        const size_t limit = 64 * 1024;
+        while (tile_bytes() > limit && in.geo.unroll > 1 && ctx->opts.tuning[1] == 0) in.geo.unroll /= 2;
+        while (tile_bytes() > limit && in.geo.threads > 128 && ctx->opts.tuning[0] == 0) in.geo.threads /= 2;
+        if (tile_bytes() > 150 * 1024)
+            fail(QE_ERR_UNSUPPORTED, "projection list too wide for the dense kernel's LDS tile (" + std::to_string(rowbytes) + " bytes per output row)");
+        plan->cg = generate_fused_source(in);
+    }
+    if (!agg_fns && in.filter && !in.dense) {
         // LDS budget of the per-wave FIFO of chunk buffers: waves * nbuf * ring * (bytes per output row).
         // Narrow rows get 3 buffers; wide rows 2 buffers and, if need be, fewer waves per workgroup so that a
         // workgroup stays within the 160 KiB of a CU (and several workgroups still fit).
@@ -616,7 +647,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
             plan->est_regs = est;
             if (((est > 168 && in.geo.unroll > 4) || (est > 300 && in.geo.unroll > 2)) && ctx->opts.tuning[1] == 0 && !wide) {
                 in.geo.unroll /= 2;
-                in.geo.subs_per_chunk *= 2;   // keep the chunk size
+                if (!in.dense) in.geo.subs_per_chunk *= 2;   // keep the chunk size (the dense kernel's chunk IS the sub-tile)
                 plan->cg = generate_fused_source(in);
                 continue;
             }
@@ -631,7 +662,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
                 in.geo.min_waves--;
             } else if (in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
                 in.geo.unroll /= 2;            // a smaller sub-tile rather than one wave per SIMD
-                in.geo.subs_per_chunk *= 2;
+                if (!in.dense) in.geo.subs_per_chunk *= 2;
                 in.geo.min_waves = 3;
             } else if (in.geo.min_waves > 1) {
                 in.geo.min_waves--;
@@ -786,10 +817,66 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     // per chunk, scan, then stream again and store every kept row straight at its final position -- no look-back, no
     // LDS ring, no staging round trip (which costs 48 B per kept row instead of 16 once the ring overflows).
     const bool force_two_pass = (ctx->opts.tuning[5] & 512) != 0, never_two_pass = (ctx->opts.tuning[5] & 1024) != 0;
-    const bool two_pass = plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
+    // DENSE single-pass form (round 2): chunk == sub-tile, outputs wait in the registers during a blocking look-back and
+    // go straight to their final position -- one read of every input, one write of every kept row at ANY selectivity.
+    // Chosen from the selectivity the plan showed last time; supersedes the two-pass form (kept behind debug bit 512).
+    const bool force_dense = (ctx->opts.tuning[5] & 16384) != 0, never_dense = (ctx->opts.tuning[5] & 32768) != 0;
+    const double dense_from = std::getenv("QE_DENSE_FROM") ? std::atof(std::getenv("QE_DENSE_FROM")) : kDenseFromSelectivity;
+    const bool dense = plan->cg.has_filter && !never_dense && !force_two_pass && (force_dense || base->last_selectivity >= dense_from);
+    const bool two_pass = !dense && plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
                           (force_two_pass || base->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6
     unsigned long long total = 0;
-    if (two_pass) {
+    if (dense) {
+        auto dplan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, false, true);
+        // a tile = the sub-tiles of one workgroup's waves; descriptors are per TILE
+        const int waves = dplan->geo.threads / 64;
+        const int64_t tile_rows = (int64_t)dplan->geo.sub_rows() * waves;
+        const int64_t nchunks = (n + tile_rows - 1) / tile_rows;
+        if (nchunks >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit tile tickets");
+        const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *dplan);
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, max_grid));
+        const int64_t nblocks = (nchunks + 63) / 64;
+        const size_t desc_words = (size_t)nchunks + 2 * (size_t)nblocks;
+        unsigned long long *desc = (unsigned long long *)ctx->pool.alloc(desc_words * 8);
+        struct DG { qe_ctx *c; void *q; ~DG() { c->pool.release(q); } } dg{ctx, desc};
+        FusedParams dp = p;                       // same inputs and outputs
+        fill_inputs(dp, batch, *dplan);           // (the dense plan has its own column slots / aux tables)
+        for (size_t i = 0; i < res->cols.size(); i++) { dp.out[i] = p.out[i]; dp.outvalid[i] = p.outvalid[i]; }
+        dp.capacity = cap;
+        dp.desc = desc;
+        dp.l1 = desc + nchunks;
+        dp.blk = desc + nchunks + nblocks;
+        dp.ticket = ctx->d_ctrl;
+        dp.error = ctx->d_ctrl + 1;
+        dp.total = (unsigned long long *)(ctx->d_ctrl + 2);
+        dp.nchunks = nchunks;
+        void *trace = nullptr;
+        struct TG { qe_ctx *c; void **q; ~TG() { c->pool.release(*q); } } tg{ctx, &trace};
+        if (ctx->opts.tuning[5] & 32) {   // diagnostic build: per tile {t_ticket, t_published, t_resolved, t_stored} in 10 ns ticks
+            trace = ctx->pool.alloc((size_t)nchunks * 32);
+            dp.trace = (unsigned long long *)trace;
+            QE_HIP(hipMemsetAsync(trace, 0, (size_t)nchunks * 32, ctx->stream));
+        }
+        QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+        QE_HIP(hipMemsetAsync(desc, 0, desc_words * 8, ctx->stream));
+        launch_fused(ctx, *dplan, dp, grid);
+        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        collect_time(ctx);
+        if (trace && std::getenv("QE_TRACE_FILE")) {
+            std::vector<unsigned long long> tr((size_t)nchunks * 4);
+            QE_HIP(hipMemcpy(tr.data(), trace, tr.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(std::getenv("QE_TRACE_FILE"), "wb")) {
+                std::fwrite(tr.data(), 8, tr.size(), f);
+                std::fclose(f);
+            }
+        }
+        const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+        if (hc[1] != 0)
+            fail(QE_ERR_INTERNAL, hc[1] == 2 ? "dense kernel: ticket grant never posted (spin limit)"
+                                             : "dense kernel: look-back spin limit reached (chunk descriptor never published)");
+        total = ctx->h_ctrl[1];
+    } else if (two_pass) {
         const int64_t chunk_rows = plan->geo.chunk_rows();
         const int waves = plan->geo.threads / 64;
         const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
@@ -921,6 +1008,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
         total = ctx->h_ctrl[1];
     }
+    ctx->last_form = !plan->cg.has_filter ? QE_FORM_NO_FILTER : dense ? QE_FORM_DENSE : two_pass ? QE_FORM_TWO_PASS : QE_FORM_RING;
     plan->last_selectivity = base->last_selectivity = (double)total / (double)n;
     if ((int64_t)total > cap)
         fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(total) + " rows but result_capacity_rows is " +
@@ -964,9 +1052,10 @@ int32_t qe_filter_project(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
     return guarded(ctx, [&] {
         need_device(ctx);
         if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
-        if (ctx->opts.exec_mode == QE_EXEC_PER_NODE)
+        if (ctx->opts.exec_mode == QE_EXEC_PER_NODE) {
             *out = run_per_node(ctx, batch, filter, projections, nproj);
-        else
+            ctx->last_form = QE_FORM_PER_NODE;
+        } else
             *out = run_fused(ctx, batch, filter, projections, nproj);
     });
 }
@@ -986,6 +1075,9 @@ int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_e
                     (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
                 } catch (const Error &) {   // optional candidate: the default plan above is what prepare guarantees
                 }
+            // the dense single-pass kernel (plans that keep a large share of their rows) is compiled ahead of time as well
+            if (filter && (ctx->opts.tuning[5] & 32768) == 0)
+                (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, false, true);
         }
     });
 }
@@ -994,7 +1086,8 @@ int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_ex
                                  const qe_expr *const *projections, int32_t nproj, const char **out) {
     if (!ctx || !batch || !out) return QE_ERR_INVALID_ARG;
     return guarded(ctx, [&] {
-        auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false);
+        const bool dense = filter && (ctx->opts.tuning[5] & 16384) != 0;   // a context forced into the dense form shows that kernel
+        auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false, nullptr, 0, false, dense);
         ctx->source_scratch = plan->cg.source;
         *out = ctx->source_scratch.c_str();
     });

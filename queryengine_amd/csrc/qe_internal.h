@@ -190,6 +190,9 @@ struct CodegenInput {
     int nt_stores = 1;    // non-temporal stores for the output rows
     int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
     bool staged = true;   // late materialisation: evaluate the filter's AND chain conjunct by conjunct, load later columns for live rows only
+    bool dense = false;   // filter+project only: generate the DENSE single-pass kernel (chunk == sub-tile, blocking look-back between
+                          // evaluation and stores, rows go from the registers straight to their final position: no LDS ring, no
+                          // staging) -- the form for plans that keep a large share of their rows
     int debug_mask = 0;   // ablation builds (wrong results): 1 no look-back, 2 no staging stores, 4 no move
 };
 
@@ -199,6 +202,7 @@ struct CodegenOutput {
     std::vector<int> used_cols;  // batch column index per kernel column slot
     bool has_filter = false;
     bool two_pass = false;       // the module also holds qe_fp_count / qe_fp_write (count + direct ordered write)
+    bool dense = false;          // the module holds the dense single-pass kernel only (entry qe_fused)
     std::vector<std::vector<int32_t>> aux_tables;   // int32 tables indexed by dictionary codes (string ranks, remaps): col[kMaxCols-1-k]
     // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
     // accumulator table geometry: ngroups rows of table_words u64 words {first row, (count, acc) per aggregate}
@@ -310,4 +314,5 @@ struct qe_ctx {
     // RCCL communicator of the exchange step (qe_comm.cpp); null until qe_comm_init
     void *comm = nullptr;
     int comm_rank = -1, comm_nranks = 0;
+    int last_form = -1;   // QE_FORM_* of the last qe_filter_project execution
 };

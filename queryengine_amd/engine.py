@@ -75,6 +75,11 @@ class Context:
     def reset_kernel_time(self) -> None:
         N.check(self.handle, self._lib.qe_ctx_reset_kernel_time(self.handle))
 
+    @property
+    def last_form(self) -> int:
+        """qe_ctx_last_form: native.FORM_* of the last filter_project on this context (-1: none yet)."""
+        return int(self._lib.qe_ctx_last_form(self.handle))
+
     def synchronize(self) -> None:
         N.check(self.handle, self._lib.qe_ctx_synchronize(self.handle))
 

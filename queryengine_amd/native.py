@@ -27,6 +27,7 @@ CMP_TOTAL_ORDER, CMP_IEEE = 0, 1
 GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE, GEN_DICT_MOD, GEN_I64_ROWID = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_COUNT, AGG_AVG = range(5)
 COMM_ID_BYTES = 128
+FORM_RING, FORM_TWO_PASS, FORM_DENSE, FORM_PER_NODE, FORM_NO_FILTER = range(5)
 
 
 class QeError(RuntimeError):
@@ -67,6 +68,7 @@ SYMBOLS = [
     ("qe_ctx_set_cmp_semantics", C.c_int32, [_P, C.c_int32]),
     ("qe_ctx_kernel_time", C.c_int32, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("qe_ctx_reset_kernel_time", C.c_int32, [_P]),
+    ("qe_ctx_last_form", C.c_int32, [_P]),
     ("qe_ctx_synchronize", C.c_int32, [_P]),
     ("qe_ctx_trim", C.c_int32, [_P]),
     ("qe_dict_create", C.c_int32, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P)]),

@@ -56,8 +56,19 @@ def gpu_ctx_two_pass(native_lib):
     ctx.close()
 
 
-@pytest.fixture(params=["fused", "per_node", "fused_two_pass"])
-def any_ctx(request, gpu_ctx, gpu_ctx_per_node, gpu_ctx_two_pass):
+@pytest.fixture(scope="session")
+def gpu_ctx_dense(native_lib):
+    """Fused executor forced into its dense single-pass form (chunk == sub-tile, blocking look-back, direct ordered stores
+    from the registers) -- normally chosen once a plan has kept >= 25 % of its rows (debug bit 16384 of tuning[5])."""
+    from queryengine_amd import engine
+    ctx = engine.Context(device=0, tuning=[0, 0, 0, 0, 0, 16384, 0, 0])
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(params=["fused", "per_node", "fused_two_pass", "fused_dense"])
+def any_ctx(request, gpu_ctx, gpu_ctx_per_node, gpu_ctx_two_pass, gpu_ctx_dense):
     """Every parity test runs through ALL execution forms, like the reference's
     @EnumSource(Mode::class) tests run through all three evaluators (CompilerTest.kt:13)."""
-    return {"fused": gpu_ctx, "per_node": gpu_ctx_per_node, "fused_two_pass": gpu_ctx_two_pass}[request.param]
+    return {"fused": gpu_ctx, "per_node": gpu_ctx_per_node, "fused_two_pass": gpu_ctx_two_pass,
+            "fused_dense": gpu_ctx_dense}[request.param]

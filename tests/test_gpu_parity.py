@@ -368,14 +368,16 @@ def test_full_size_bench_workloads_properties(gpu_ctx, oracle, name):
     gpu_ctx.trim()
 
 
-def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
-    """The fused executor remembers the selectivity a plan showed: the first execution is single-pass, the next one of a
-    high-selectivity plan runs count -> scan -> direct write.  Both give the reference's rows in input order."""
+def test_dense_form_is_chosen_after_a_high_selectivity_run(oracle):
+    """The fused executor remembers the share of rows a plan kept: the first execution runs the LDS-ring single pass, the
+    next one of a plan that kept >= 12 % runs the dense single pass (a workgroup per tile, one tile parked in LDS, resolved
+    one tile later, coalesced ordered stores); a selective plan stays with the ring.  All give the reference's rows in input
+    order.  Several tiles per workgroup and ragged tails (n is not a multiple of the tile)."""
     from queryengine_amd import engine as E
     from queryengine_amd import workloads as W
-    n = 150_001
+    n = 2_500_001
     ctx = E.Context(device=0)
-    for a_limit, c_limit in ((1000, 1.0), (1000, 0.5), (100, 0.5)):
+    for a_limit, c_limit, want_form in ((1000, 1.0, N.FORM_DENSE), (1000, 0.5, N.FORM_DENSE), (300, 0.5, N.FORM_DENSE), (100, 0.5, N.FORM_RING)):
         wl = W.config2(n, a_limit=a_limit, c_limit=c_limit, null_pct=1)
         batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
         host = [batch.column_to_host(j) for j in range(batch.ncols)]
@@ -383,6 +385,7 @@ def test_two_pass_form_is_chosen_after_a_high_selectivity_run(oracle):
         cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
         for rep in range(3):
             res = E.filter_project(ctx, batch, cf, cp)
+            assert ctx.last_form == (N.FORM_RING if rep == 0 else want_form)
             got = res.to_columns()
             res.free()
             for g, w in zip(got, want):

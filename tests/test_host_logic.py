@@ -319,3 +319,21 @@ def test_int_compare_shortcut_stops_below_2_53(plan_ctx):
         text = src(lit)
         assert "ll)" not in text.split("qe_conj0")[1].split("}")[0], lit     # no integer literal compare in the conjunct
         assert "((double)c0)" in text
+
+
+def test_dense_single_pass_kernel_is_generated_and_compiles(native_lib, tmp_path):
+    """The dense form (plans that keep a large share of their rows): a workgroup per tile of QE_WAVES sub-tiles, the kept rows of a
+    tile parked in the workgroup's LDS tile while the next tile is loaded, resolved one tile later and moved with coalesced
+    stores.  Generated
+    and hiprtc-compiled for the BASELINE plans on a planning-only context (no GPU)."""
+    from queryengine_amd import workloads as W
+    from queryengine_amd.prepared import _schema_columns
+    ctx = E.Context(device=None, jit_cache_dir=str(tmp_path), tuning=[0, 0, 0, 0, 0, 16384, 0, 0])
+    for wl in (W.config2(1000), W.config2(1000, null_pct=1), W.config3(1000), W.config4(1000)):
+        batch = E.DeviceBatch.describe(ctx, _schema_columns(wl))
+        cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
+        src = E.generated_source(ctx, batch, cf, cp)
+        assert "s_ticket" in src and "qe_dense_load<true>" in src and "qe_lookback_wait(p, ptile, lb, lane)" in src and "qe_dense_park(" in src
+        assert "qe_conj0(" not in src and "QE_SUBS_PER_CHUNK 1u" in src       # every load up front, chunk == sub-tile
+        E.prepare(ctx, batch, cf, cp)      # compiles the default, the wide AND the dense kernel
+    ctx.close()
