@@ -370,15 +370,23 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         if (ctx->opts.result_capacity_rows > 0 && m > ctx->opts.result_capacity_rows)   // same contract as the fused path
             fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(m) + " rows but result_capacity_rows is " +
                                          std::to_string(ctx->opts.result_capacity_rows));
+        // 3. gather the referenced columns at the kept row ids: value columns in one launch per 8 columns (the ids are read
+        //    once), bitmap columns (BOOLEAN values, validity) bit by bit
         Buf idx = x.alloc((size_t)std::max<int64_t>(m, 1) * 4);
         pn::expand_indices(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
                            (const uint32_t *)offsets.get(), (uint32_t *)idx.get(), nw);
-        // 3. gather the referenced columns at the kept row ids
         std::vector<char> used(x.env.size(), 0);
         for (int32_t i = 0; i < nproj; i++) collect_columns(projs[i]->e, used);
         std::vector<Vec> compact(x.env.size());
         const int64_t full_n = x.n;
         x.n = m;
+        pn::GatherArgs ga{};
+        ga.idx = (const uint32_t *)idx.get();
+        ga.m = m;
+        auto flush = [&]() {
+            if (ga.ncols > 0 && m > 0) pn::gather_multi(x.s, ga);
+            ga.ncols = 0;
+        };
         for (size_t j = 0; j < x.env.size(); j++) {
             compact[j].type = x.env[j].type;
             compact[j].dict = x.env[j].dict;
@@ -389,13 +397,17 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
                 pn::gather_bits(x.s, (const uint64_t *)src.data.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].data.get(), m);
             } else {
                 compact[j].data = x.alloc_col(src.type);
-                pn::gather(x.s, kernel_type(src.type), src.data.get(), (const uint32_t *)idx.get(), compact[j].data.get(), m);
+                ga.src[ga.ncols] = src.data.get();
+                ga.dst[ga.ncols] = compact[j].data.get();
+                ga.width[ga.ncols] = (int)width_of(src.type);
+                if (++ga.ncols == 8) flush();
             }
             if (src.valid) {
                 compact[j].valid = x.alloc_words();
                 pn::gather_bits(x.s, (const uint64_t *)src.valid.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].valid.get(), m);
             }
         }
+        flush();
         (void)full_n;
         x.env.swap(compact);
     } else if (ctx->opts.profile) {

@@ -41,6 +41,16 @@ void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint32
                         unsigned long long *total);
 void expand_indices(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t n, const uint32_t *word_offsets,
                     uint32_t *indices, int64_t nwords);
+// gather of up to 8 value columns (4- or 8-byte elements) at the kept row ids in ONE launch (the ids are read once)
+struct GatherArgs {
+    const void *src[8];
+    void *dst[8];
+    int width[8];
+    int ncols;
+    const uint32_t *idx;
+    long long m;
+};
+void gather_multi(hipStream_t s, const GatherArgs &a);
 void gather(hipStream_t s, int type, const void *src, const uint32_t *idx, void *out, int64_t m);
 void gather_bits(hipStream_t s, const uint64_t *src, const uint32_t *idx, uint64_t *out, int64_t m);
 // out[i] = table[codes[i]] (a code outside the table -- the garbage under a NULL -- reads as -1): string ranks / code remaps

@@ -7,6 +7,7 @@
 // Double.compare / equals) exactly as the fused kernels do; validity is handled
 // by the executor with word-parallel bitmap kernels (k = ka & kb etc.).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "qe_pernode_kernels.h"
 #include "../../include/qe_hip.h"
@@ -66,14 +67,50 @@ template <int OP> struct ArithOp<int, OP> {
     }
 };
 
+// Two rows per lane and load: 16 bytes for the 8-byte types (global_load_dwordx4, 1 KiB contiguous per wave instruction),
+// 4 pairs in flight per lane before the first use; a scalar operand lives in SGPRs (no column of copies).
+template <typename T> struct Pair { T x, y; };
+template <typename T> struct V2;
+template <> struct V2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct V2<i64> { typedef i64 type __attribute__((ext_vector_type(2))); };
+template <> struct V2<int> { typedef int type __attribute__((ext_vector_type(2))); };
+template <typename T> using Vec2 = typename V2<T>::type;
+
+template <typename T> __device__ __forceinline__ Pair<T> ld2(const Ld<T> &a, i64 pair) {
+    if (!a.p) return Pair<T>{a.s, a.s};
+    const Vec2<T> v = __builtin_nontemporal_load((const Vec2<T> *)a.p + pair);
+    return Pair<T>{v.x, v.y};
+}
+
 template <typename T, int OP>
 __global__ void __launch_bounds__(256) k_arith(Ld<T> a, Ld<T> b, T *out, i64 n) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = ArithOp<T, OP>::apply(a[i], b[i]);
+    const i64 npairs = n >> 1;
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < npairs; i += 4 * stride) {
+        Pair<T> x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = ld2(a, i + j * stride); y[j] = ld2(b, i + j * stride); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Vec2<T> r;
+            r.x = ArithOp<T, OP>::apply(x[j].x, y[j].x);
+            r.y = ArithOp<T, OP>::apply(x[j].y, y[j].y);
+            ((Vec2<T> *)out)[i + j * stride] = r;
+        }
+    }
+    for (; i < npairs; i += stride) {
+        const Pair<T> x = ld2(a, i), y = ld2(b, i);
+        Vec2<T> r;
+        r.x = ArithOp<T, OP>::apply(x.x, y.x);
+        r.y = ArithOp<T, OP>::apply(x.y, y.y);
+        ((Vec2<T> *)out)[i] = r;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = ArithOp<T, OP>::apply(a[n - 1], b[n - 1]);
 }
 
 template <typename T> static void arith_t(hipStream_t s, int op, const Opnd &a, const Opnd &b, void *out, int64_t n) {
-    const int g = grid_for(n);
+    const int g = grid_for((n + 1) / 2, 256, 256 * 8);
     Ld<T> la = mk<T>(a), lb = mk<T>(b);
     switch (op) {
     case A_ADD: hipLaunchKernelGGL((k_arith<T, A_ADD>), dim3(g), dim3(256), 0, s, la, lb, (T *)out, (i64)n); break;
@@ -178,29 +215,84 @@ template <int CMP> struct CmpOp<double, CMP, 1> {   // CLOSURE_COMPILER: IEEE <,
     }
 };
 
-// one thread per row, one wave per 64 rows: the result word IS the __ballot
-template <typename T, int CMP, int IEEE>
+// A wave handles chunks of 4 adjacent groups of 128 rows (4 KiB of an 8-byte column): lane l loads rows 2l, 2l+1 of each
+// group with ONE load (16 bytes for the 8-byte types, 1 KiB contiguous per wave instruction), all 4 in flight before the
+// first use.  Lane l holds the results of rows 2l, 2l+1; word 0 of a group (rows 0..63) wants row i in bit i: lane i fetches
+// the pair of lane i >> 1 (word 1: lane 32 + (i >> 1)) with a cross-lane permute and ballots its bit i & 1.  The chunk's 8
+// result words leave in ONE store instruction (lanes 0..7, 64 contiguous bytes): a store per word from a single lane kept
+// the address unit busy for a whole wave instruction each (15.6 M of them per 1 B rows: 1.6 - 1.9 ms per 8 GB column
+// instead of 1.3), and so did interleaving the even / odd ballots with scalar bit tricks (~60 SALU instructions per group
+// on the CU's one scalar unit).  Row i = word i >> 6, bit i & 63; bits past the last row are 0.
+template <typename T, int CMP, int IEEE, int K>
 __global__ void __launch_bounds__(256) k_cmp(Ld<T> a, Ld<T> b, u64 *out, i64 n) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const i64 padded = (n + 63) & ~63ll;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
-        const bool r = i < n && CmpOp<T, CMP, IEEE>::apply(a[i < n ? i : 0], b[i < n ? i : 0]);
-        const u64 w = __ballot(r);
-        if ((threadIdx.x & 63) == 0) out[i >> 6] = w;
+    const int lane = threadIdx.x & 63;
+    const i64 cstride = (i64)gridDim.x * (blockDim.x >> 6);
+    const i64 nchunks = (n + 511) >> 9, nfull = n >> 9;
+    const i64 nw = (n + 63) >> 6;
+    const int src0 = (lane >> 1) << 2, src1 = (32 + (lane >> 1)) << 2;
+    // K chunks (a grid stride apart) per step: 4 K loads per operand in flight per lane
+    for (i64 c0 = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c0 < nchunks; c0 += K * cstride) {
+        int pair[K][4];
+        if (c0 + (K - 1) * cstride < nfull) {
+            Pair<T> x[K][4], y[K][4];
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[q][j] = ld2(a, ((c0 + q * cstride) * 4 + j) * 64 + lane);
+                    y[q][j] = ld2(b, ((c0 + q * cstride) * 4 + j) * 64 + lane);
+                }
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    pair[q][j] = (CmpOp<T, CMP, IEEE>::apply(x[q][j].x, y[q][j].x) ? 1 : 0) | (CmpOp<T, CMP, IEEE>::apply(x[q][j].y, y[q][j].y) ? 2 : 0);
+        } else {   // near the ragged end: row by row
+            // (written with explicit flags: `if (r < n && apply(..)) pair |= 1` came out of hipcc 7.2 with a scalar-mask
+            //  sequence that lost the Double.compare tie-break of the even rows -- caught by the special-values parity test)
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i64 r = ((c0 + q * cstride) * 4 + j) * 128 + 2 * lane;
+                    bool r0 = false, r1 = false;
+                    if (r < n) r0 = CmpOp<T, CMP, IEEE>::apply(a[r], b[r]);
+                    if (r + 1 < n) r1 = CmpOp<T, CMP, IEEE>::apply(a[r + 1], b[r + 1]);
+                    pair[q][j] = (r0 ? 1 : 0) | (r1 ? 2 : 0);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const i64 c = c0 + q * cstride;
+            u64 mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p0 = __builtin_amdgcn_ds_bpermute(src0, pair[q][j]);
+                const int p1 = __builtin_amdgcn_ds_bpermute(src1, pair[q][j]);
+                const u64 w0 = __ballot((p0 >> (lane & 1)) & 1);
+                const u64 w1 = __ballot((p1 >> (lane & 1)) & 1);
+                if (lane == 2 * j) mine = w0;
+                if (lane == 2 * j + 1) mine = w1;
+            }
+            if (lane < 8 && c * 8 + lane < nw) out[c * 8 + lane] = mine;
+        }
     }
 }
 
-template <typename T, int IEEE> static void cmp_t(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
-    const int g = grid_for(n);
+template <typename T, int IEEE, int K> static void cmp_tk(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
+    const int g = grid_for((n + 511) / 512, 4, 256 * 8);   // 4 waves per workgroup, K 512-row chunks per wave and step
     Ld<T> la = mk<T>(a), lb = mk<T>(b);
     switch (cmp) {
-    case C_LT: hipLaunchKernelGGL((k_cmp<T, C_LT, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
-    case C_LE: hipLaunchKernelGGL((k_cmp<T, C_LE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
-    case C_GE: hipLaunchKernelGGL((k_cmp<T, C_GE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
-    case C_GT: hipLaunchKernelGGL((k_cmp<T, C_GT, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
-    case C_EQ: hipLaunchKernelGGL((k_cmp<T, C_EQ, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
-    default: hipLaunchKernelGGL((k_cmp<T, C_NE, IEEE>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_LT: hipLaunchKernelGGL((k_cmp<T, C_LT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_LE: hipLaunchKernelGGL((k_cmp<T, C_LE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_GE: hipLaunchKernelGGL((k_cmp<T, C_GE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_GT: hipLaunchKernelGGL((k_cmp<T, C_GT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    case C_EQ: hipLaunchKernelGGL((k_cmp<T, C_EQ, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+    default: hipLaunchKernelGGL((k_cmp<T, C_NE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
     }
+}
+template <typename T, int IEEE> static void cmp_t(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
+    cmp_tk<T, IEEE, 1>(s, cmp, a, b, out, n);   // K = 2 (8 loads per operand in flight) measured the same: 1.34 - 1.41 ms per 8 GB
 }
 
 void compare(hipStream_t s, int type, int cmp, int ieee, Opnd a, Opnd b, uint64_t *out, int64_t n) {
@@ -399,24 +491,67 @@ void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint32
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks), dim3(1024), 0, s, in, block_sums, out, (i64)n);
 }
 
-// one wave per bitmap word: lane l emits row 64*w + l at offset[w] + popcount(bits below l)
+// A LANE per bitmap word: lane l walks the set bits of word w0 + l and writes their row ids from word_offsets[w] on.  The 64
+// words of a wave are adjacent and so are their output ranges, so step i of the walk is one store instruction with every
+// lane that still has a bit active, all within a few hundred bytes.  (One wave per word -- lanes = bits -- issued a store
+// instruction with ~3 active lanes per word at 5 % selectivity: 1.43 ms per 1 B rows.)
 __global__ void __launch_bounds__(256) k_expand_indices(const u64 *v, const u64 *k, i64 n, const u32 *word_offsets,
                                                         u32 *indices, i64 nw) {
-    const int lane = threadIdx.x & 63;
-    const i64 wstride = (i64)gridDim.x * (blockDim.x >> 6);
-    for (i64 w = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < nw; w += wstride) {
-        const u64 x = keep_word(v, k, w, n);
-        if ((x >> lane) & 1ull) {
-            const u32 below = (u32)__popcll(x & ((1ull << lane) - 1ull));
-            indices[word_offsets[w] + below] = (u32)(w * 64 + lane);
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
+        u64 x = keep_word(v, k, w, n);
+        u32 pos = word_offsets[w];
+        const u32 base = (u32)(w * 64);
+        while (x != 0) {
+            indices[pos++] = base + (u32)__builtin_ctzll(x);
+            x &= x - 1;
         }
     }
 }
 void expand_indices(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t n, const uint32_t *word_offsets,
                     uint32_t *indices, int64_t nw) {
     if (nw <= 0) return;
-    hipLaunchKernelGGL(k_expand_indices, dim3(grid_for(nw, 4)), dim3(256), 0, s, (const u64 *)v, (const u64 *)k, (i64)n,
+    hipLaunchKernelGGL(k_expand_indices, dim3(grid_for(nw, 256, 256 * 8)), dim3(256), 0, s, (const u64 *)v, (const u64 *)k, (i64)n,
                        word_offsets, indices, (i64)nw);
+}
+
+// Gather of up to 8 value columns at the kept row ids, one output row per lane and step, 4 rows in flight per lane: every
+// lane of every load carries a row (a masked one-row-per-lane compaction straight from the bitmap was measured 2.8x
+// slower at 5 % selectivity: the address unit spends its cycles per wave instruction, not per active lane).
+__global__ void __launch_bounds__(256) k_gather_multi(const GatherArgs a) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; j + 3 * stride < a.m; j += 4 * stride) {
+        u32 r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = __builtin_nontemporal_load(a.idx + j + q * stride);
+        for (int c = 0; c < a.ncols; ++c) {
+            if (a.width[c] == 8) {
+                u64 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ((const u64 *)a.src[c])[r[q]];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ((u64 *)a.dst[c])[j + q * stride] = v[q];
+            } else {
+                u32 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ((const u32 *)a.src[c])[r[q]];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ((u32 *)a.dst[c])[j + q * stride] = v[q];
+            }
+        }
+    }
+    for (; j < a.m; j += stride) {
+        const u32 r = a.idx[j];
+        for (int c = 0; c < a.ncols; ++c) {
+            if (a.width[c] == 8) ((u64 *)a.dst[c])[j] = ((const u64 *)a.src[c])[r];
+            else ((u32 *)a.dst[c])[j] = ((const u32 *)a.src[c])[r];
+        }
+    }
+}
+void gather_multi(hipStream_t s, const GatherArgs &a) {
+    if (a.m <= 0 || a.ncols <= 0) return;
+    hipLaunchKernelGGL(k_gather_multi, dim3(grid_for((a.m + 3) / 4, 256, 256 * 8)), dim3(256), 0, s, a);
 }
 
 template <typename T> __global__ void __launch_bounds__(256) k_gather(const T *src, const u32 *idx, T *out, i64 m) {
