@@ -591,6 +591,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
     auto plan = std::make_shared<Plan>();
     plan->cg = generate_fused_source(in);
+    if (plan->cg.hashed && ctx->opts.tuning[1] == 0 && in.geo.unroll > 4) {
+        in.geo.unroll = 4;   // hashed group-by: the key words of 2 * U rows live in registers next to the inputs; it is bound by atomics, not by loads in flight
+        plan->cg = generate_fused_source(in);
+    }
     if (in.dense) {
         // LDS budget of the parked tile: (waves * 128 * U) rows of every output column.  64 KiB lets two workgroups share a
         // CU (the second one streams while the first waits at its barriers); shrink the sub-tile, then the workgroup.
@@ -1041,6 +1045,154 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     return res.release();
 }
 
+// GroupByAggregation over arbitrary key tuples (a DOUBLE / INT64 / INT32 key, or more key combinations than a dense table
+// holds): the hashed form.  Global open-addressing table, grown (x8) and the kernel run again when it got more than half
+// full; the used entries are collected on the device, sorted by smallest row id on the host (LinkedHashMap insertion order,
+// GroupByAggregationOperator.kt:22) and finished like the dense form's (Accumulators.kt:26-107).
+qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const int32_t *agg_fns, int32_t nagg) {
+    const CodegenOutput &cg = plan.cg;
+    const int W = cg.hash_words, NK = (int)cg.keys.size(), ACC = 2 + NK;
+    if (W > 40) fail(QE_ERR_UNSUPPORTED, "too many GROUP BY keys + aggregates for one hash entry");
+    const int64_t n = batch->nrows;
+    HtInit init{};
+    init.words = W;
+    for (int w = 0; w < W; w++) init.word[w] = 0;
+    init.word[ACC] = ~0ull;   // smallest row id
+    for (int i = 0; i < nagg; i++)
+        init.word[ACC + 2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
+    std::vector<unsigned long long> dense;
+    int64_t m = 0;
+    if (n > 0) {
+        int64_t C = plan.hash_capacity > 0 ? plan.hash_capacity : (1ll << 16);
+        for (;;) {
+            unsigned long long *d_tab = (unsigned long long *)ctx->pool.alloc((size_t)C * W * 8);
+            struct G1 { qe_ctx *c; void *p; ~G1() { c->pool.release(p); } } g1{ctx, d_tab};
+            launch_ht_init(ctx->stream, d_tab, C, init);
+            QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));   // [0] entries in use (p.ticket), [1] error (p.error)
+            const int64_t sub_rows = plan.geo.sub_rows();
+            const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
+            const int waves = plan.geo.threads / 64;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 4));
+            FusedParams p;
+            fill_inputs(p, batch, plan);
+            p.agg_partial = (double *)d_tab;
+            p.capacity = C;
+            p.ticket = ctx->d_ctrl;
+            p.error = ctx->d_ctrl + 1;
+            launch_fused(ctx, plan, p, grid);
+            QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            collect_time(ctx);
+            const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+            if (hc[1] != 0) {   // more than half full (or a probe sequence ran out): a bigger table, again
+                if (C >= (1ll << 28)) fail(QE_ERR_UNSUPPORTED, "GROUP BY produced more than 2^27 groups");
+                C *= 8;
+                continue;
+            }
+            plan.hash_capacity = C;
+            const int64_t used = hc[0];
+            unsigned long long *d_dense = (unsigned long long *)ctx->pool.alloc((size_t)std::max<int64_t>(used, 1) * W * 8);
+            struct G2 { qe_ctx *c; void *p; ~G2() { c->pool.release(p); } } g2{ctx, d_dense};
+            QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));
+            launch_ht_collect(ctx->stream, d_tab, C, W, d_dense, ctx->d_ctrl);
+            dense.resize((size_t)used * W);
+            if (used > 0) QE_HIP(hipMemcpyAsync(dense.data(), d_dense, dense.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipGetLastError());
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            m = used;
+            break;
+        }
+    }
+    std::vector<std::pair<unsigned long long, int64_t>> order;
+    order.reserve((size_t)m);
+    for (int64_t g = 0; g < m; g++) order.emplace_back(dense[(size_t)g * W + ACC], g);
+    std::sort(order.begin(), order.end());
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
+    res->count = m;
+    res->capacity = m;
+    const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
+    auto upload = [&](const void *src, size_t bytes) -> void * {
+        void *d = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        if (bytes) QE_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return d;
+    };
+    std::vector<std::vector<unsigned long long>> keep64;   // host staging must outlive the async copies
+    std::vector<std::vector<int32_t>> keep32;
+    for (int k = 0; k < NK; k++) {
+        OutColumn oc;
+        oc.type = cg.keys[k].type;
+        oc.dict = cg.keys[k].dict;
+        oc.dict_handle.d = oc.dict;
+        std::vector<unsigned long long> valid(words, 0), vals64((size_t)std::max<int64_t>(m, 1), 0), bits(words, 0);
+        std::vector<int32_t> vals32((size_t)std::max<int64_t>(m, 1), 0);
+        bool any_null = false;
+        for (int64_t j = 0; j < m; j++) {
+            const unsigned long long *e = &dense[(size_t)order[j].second * W];
+            if ((e[1] >> k) & 1ull) { any_null = true; continue; }
+            valid[j >> 6] |= 1ull << (j & 63);
+            const unsigned long long kw = e[2 + k];
+            vals64[j] = kw;                       // DOUBLE: the canonical bits ARE the value; INT64: the value
+            vals32[j] = (int32_t)(int64_t)kw;     // INT32 / dictionary codes
+            if (kw) bits[j >> 6] |= 1ull << (j & 63);
+        }
+        oc.nullable = any_null;
+        if (oc.type == QE_BOOLEAN) {
+            keep64.push_back(bits);
+            oc.data = upload(keep64.back().data(), words * 8);
+        } else if (oc.type == QE_DOUBLE || oc.type == QE_INT64) {
+            keep64.push_back(vals64);
+            oc.data = upload(keep64.back().data(), (size_t)m * 8);
+        } else {
+            keep32.push_back(vals32);
+            oc.data = upload(keep32.back().data(), (size_t)m * 4);
+        }
+        if (any_null) {
+            keep64.push_back(valid);
+            oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
+        }
+        res->cols.push_back(oc);
+    }
+    std::vector<std::vector<double>> keep_vals;
+    for (int i = 0; i < nagg; i++) {
+        OutColumn oc;
+        oc.type = QE_DOUBLE;
+        std::vector<double> vals((size_t)std::max<int64_t>(m, 1), 0.0);
+        std::vector<unsigned long long> valid(words, 0);
+        bool any_null = false;
+        for (int64_t j = 0; j < m; j++) {
+            const unsigned long long *e = &dense[(size_t)order[j].second * W] + ACC;   // {first row, (count, acc)..}
+            const unsigned long long cnt = e[1 + 2 * cg.cnt_src[i]];
+            const unsigned long long raw = e[2 + 2 * i];
+            double v = 0.0;
+            bool ok = true;
+            switch (agg_fns[i]) {
+            case QE_AGG_COUNT: v = (double)cnt; break;                       // Accumulators.kt:26-36
+            case QE_AGG_SUM: std::memcpy(&v, &raw, 8); ok = cnt != 0; break;  // :47-53 empty => null
+            case QE_AGG_AVG: std::memcpy(&v, &raw, 8); ok = cnt != 0; if (ok) v /= (double)cnt; break;
+            default: {                                                        // MIN / MAX: undo the ordered key
+                long long key = (long long)raw;
+                long long b = key ^ ((key >> 63) & 0x7fffffffffffffffll);
+                std::memcpy(&v, &b, 8);
+                ok = cnt != 0;
+            }
+            }
+            if (ok) valid[j >> 6] |= 1ull << (j & 63);
+            else { any_null = true; v = 0.0; }
+            vals[j] = v;
+        }
+        oc.nullable = any_null;
+        keep_vals.push_back(vals);
+        oc.data = upload(keep_vals.back().data(), (size_t)m * 8);
+        if (any_null) {
+            keep64.push_back(valid);
+            oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
+        }
+        res->cols.push_back(oc);
+    }
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    return res.release();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1202,6 +1354,10 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
         auto plan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true, keys, nkeys);
         const CodegenOutput &cg = plan->cg;
+        if (cg.hashed) {
+            *out = run_groupby_hashed(ctx, batch, *plan, agg_fns, nagg);
+            return;
+        }
         const int64_t G = cg.ngroups;
         const int W = cg.table_words;
         // global accumulator table, initialised from the host (smallest row = ~0, MIN/MAX keys at their identity)

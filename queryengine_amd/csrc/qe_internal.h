@@ -211,6 +211,9 @@ struct CodegenOutput {
     long long ngroups = 0;
     int table_words = 0;
     bool table_in_lds = false;
+    bool hashed = false;         // group-by over arbitrary key tuples (a DOUBLE / INT64 / INT32 key, or too many combinations for a
+                                 // dense table): open-addressing hash table, entry = hash_words u64 words
+    int hash_words = 0;          // {state, null bits, key words.., first row, (count, acc)..}
     int table_copies = 1;        // global group table: copies merged on the host (one per XCD)
     std::vector<int> cnt_src;    // per aggregate: the aggregate whose count word holds its count (non-nullable inputs all
                                  // see every kept row of the group: they share the first one's counter, one atomic less each)
@@ -259,6 +262,7 @@ struct Plan {
     mutable std::vector<void *> aux_dev;      // device copies of cg.aux_tables (uploaded at the first execution)
     ~Plan() { for (void *q : aux_dev) (void)hipFree(q); }
     mutable double last_selectivity = -1.0;   // kept / scanned rows of the last execution (picks the two-pass form)
+    mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
     int est_regs = 0;                         // register estimate of the plan's geometry (get_plan)
     bool explicit_geometry = false;           // unroll / chunk / ring were fixed through qe_options.tuning
 };

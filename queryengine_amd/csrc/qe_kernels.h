@@ -36,6 +36,16 @@ struct GbAggArgs {
 };
 void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a);
 
+// hashed group-by: fill a table of nentries entries with the per-word pattern of an empty entry; copy the entries in use
+// (state word == 2) to a dense array, *counter = how many
+struct HtInit {
+    int words;
+    unsigned long long word[40];
+};
+void launch_ht_init(hipStream_t s, unsigned long long *tab, int64_t nentries, const HtInit &init);
+void launch_ht_collect(hipStream_t s, const unsigned long long *tab, int64_t nentries, int words, unsigned long long *dense,
+                       unsigned int *counter);
+
 // place nbits bits of src at bit offset dst_bit_offset of dst (bitmap words; concatenation of results / gather)
 void launch_bitmap_place(hipStream_t s, uint64_t *dst, int64_t dst_bit_offset, const uint64_t *src, int64_t nbits);
 

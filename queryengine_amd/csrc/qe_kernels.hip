@@ -381,4 +381,35 @@ void launch_bitmap_place(hipStream_t s, uint64_t *dst, int64_t dst_bit_offset, c
                        (i64)dst_bit_offset, (const u64 *)src, (i64)nbits);
 }
 
+// ---- hashed group-by: table initialisation and collection of the used entries ---------------------------------------------
+__global__ void __launch_bounds__(256) ht_init_kernel(u64 *tab, i64 nentries, HtInit init) {
+    const i64 total = nentries * init.words;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) tab[i] = init.word[i % init.words];
+}
+void launch_ht_init(hipStream_t s, unsigned long long *tab, int64_t nentries, const HtInit &init) {
+    if (nentries <= 0) return;
+    const int64_t blocks = (nentries * init.words + 255) / 256;
+    hipLaunchKernelGGL(ht_init_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, (u64 *)tab, (i64)nentries, init);
+}
+// every READY entry (state word == 2) is copied to dense[slot], slot drawn from *counter (order: irrelevant, the host sorts
+// the groups by their smallest row id)
+__global__ void __launch_bounds__(256) ht_collect_kernel(const u64 *tab, i64 nentries, int words, u64 *dense, unsigned int *counter) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < nentries; e += stride) {
+        const u64 *src = tab + e * words;
+        if (src[0] != 2ull) continue;
+        const u32 slot = atomicAdd(counter, 1u);
+        u64 *dst = dense + (i64)slot * words;
+        for (int w = 0; w < words; ++w) dst[w] = src[w];
+    }
+}
+void launch_ht_collect(hipStream_t s, const unsigned long long *tab, int64_t nentries, int words, unsigned long long *dense,
+                       unsigned int *counter) {
+    if (nentries <= 0) return;
+    const int64_t blocks = (nentries + 255) / 256;
+    hipLaunchKernelGGL(ht_collect_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, (const u64 *)tab, (i64)nentries,
+                       words, (u64 *)dense, counter);
+}
+
 }  // namespace qe

@@ -259,3 +259,101 @@ def test_group_by_counter_sharing_with_mixed_nullability(path, oracle):
                     assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
     batch.free()
     ctx.close()
+
+
+def _rows_equal(got, want, nkeys, aggs, oracle):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for a, b in zip(g[:nkeys], w[:nkeys]):                 # same groups, same (insertion) order; Double.equals on keys
+            if isinstance(b, float):
+                assert a is not None and (a == b and np.signbit(a) == np.signbit(b) or (a != a and b != b)), (g, w)
+            else:
+                assert a == b, (g, w)
+        for a, b, fn in zip(g[nkeys:], w[nkeys:], aggs):
+            if b is None or fn != oracle.AVG:
+                assert a == b or (a != a and b != b), (g, w)
+            else:
+                assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("case", ["double_specials", "int64_many", "mixed_keys", "grows"])
+def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
+    """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
+    Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
+    (all NaNs one group, -0.0 and 0.0 two groups), NULL is a key; groups in the reference's insertion order; few keys stay
+    in the workgroups' LDS tables, many go through the global table, which grows when more than half full."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(77)
+    ctx = E.Context(device=0)
+    I32 = DataType.INT32
+    if case == "double_specials":
+        n = 150_001
+        pool = np.array([0.0, -0.0, 1.0, 2.5, float("nan"), float("inf"), -float("inf"), 6.0, -1.0,
+                         np.frombuffer(np.uint64(0x7ff8000000000123).tobytes(), dtype=np.float64)[0]])   # a NaN with a payload
+        k = Column(D, pool[rng.integers(0, len(pool), n)], rng.random(n) > 0.03)
+        keys = [ColumnExpression("k", 0, D)]
+        cols = [k]
+    elif case == "int64_many":
+        n = 600_011
+        k = Column(I64, rng.integers(-2 ** 62, 2 ** 62, 150_000)[rng.integers(0, 150_000, n)], rng.random(n) > 0.01)
+        keys = [ColumnExpression("k", 0, I64)]
+        cols = [k]
+    elif case == "grows":
+        n = 900_001                                           # ~570 k distinct keys: the 65 536-entry table grows twice
+        k = Column(I32, rng.integers(0, 1_000_000, n).astype(np.int32))
+        keys = [ColumnExpression("k", 0, I32)]
+        cols = [k]
+    else:
+        n = 250_003
+        d = ["k%02d" % i for i in range(9)]
+        s = Column(S, rng.integers(0, len(d), n).astype(np.int32), rng.random(n) > 0.05, d)
+        k = Column(D, np.round(rng.normal(0, 3, n)), rng.random(n) > 0.05)
+        b = Column(B, rng.random(n) > 0.5)
+        keys = [ColumnExpression("s", 0, S), FunctionExpression(Function.MUL, [ColumnExpression("k", 1, D), NumericLiteralExpression(0.5)], D),
+                ColumnExpression("b", 2, B)]
+        cols = [s, k, b]
+    x = Column(D, np.round(rng.normal(0, 100, n)), rng.random(n) > 0.2)       # integer valued: sums exact in any order
+    y = Column(I64, rng.integers(-1000, 1000, n))
+    nc = len(cols)
+    X, Y = ColumnExpression("x", nc, D), ColumnExpression("y", nc + 1, I64)
+    cols = cols + [x, y]
+    exprs = [X, X, X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)]
+    aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
+    flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
+    batch = E.DeviceBatch.from_columns(ctx, cols)
+    for f in (None, flt):
+        for rep in range(2):                                  # the second run starts with the capacity that sufficed
+            res = E.filter_groupby(ctx, batch, ctx.compile(f) if f is not None else None,
+                                   [ctx.compile(kk) for kk in keys], [ctx.compile(e) for e in exprs], aggs)
+            cs = res.to_columns()
+            got = [[c.value(i) for c in cs] for i in range(res.count)]
+            res.free()
+        want = oracle.filter_groupby(cols, f, keys, exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert len(want) > (5 if case != "double_specials" else 9)
+        _rows_equal(got, want, len(keys), aggs, oracle)
+    batch.free()
+    ctx.close()
+
+
+def test_tripdata_query_shape_group_by_double_column(gpu_ctx):
+    """Tripdata.kt:27-31: SELECT passenger_count, MIN(fare_amount), MAX(fare_amount) FROM tripdata -- grouping by a DOUBLE
+    column, through query() and the planner (implicit GROUP BY, RewriteAggregates.kt:21-47)."""
+    from queryengine_amd import ColumnarTable, Field, Schema, TableRegistry
+    from queryengine_amd.planner import Mode, query
+    rng = np.random.default_rng(3)
+    n = 50_000
+    pc = rng.integers(0, 7, n).astype(np.float64)
+    fare = np.round(rng.uniform(2.5, 80.0, n), 2)
+    t = ColumnarTable(Schema([Field("passenger_count", D), Field("fare_amount", D)]), [Column(D, pc), Column(D, fare)])
+    reg = TableRegistry()
+    reg.register("tripdata", t)
+    rows = query(reg, "SELECT passenger_count, MIN(fare_amount), MAX(fare_amount) FROM tripdata", Mode.GPU_FUSED, ctx=gpu_ctx)
+    seen = []
+    for v in pc:
+        if v not in seen:
+            seen.append(v)
+    assert [r[0] for r in rows] == seen                        # LinkedHashMap insertion order
+    for key, lo, hi in rows:
+        sel = fare[pc == key]
+        assert lo == sel.min() and hi == sel.max()

@@ -27,3 +27,21 @@ for nkeys in KEYS:
         print(f"GROUP BY s ({nkeys} keys){' WHERE v < 0.5' if f is not None else ''}: groups {ng} kernel {ms:.3f} ms "
               f"{rows * 12 / ms / 1e6:.0f} GB/s ({rows / ms / 1e6:.1f} G rows/s)", flush=True)
     b.free(); ctx.close()
+
+# Tripdata.kt:27-31 shape: SELECT passenger_count, MIN(fare_amount), MAX(fare_amount) -- grouping by a DOUBLE column (hashed form)
+from queryengine_amd.workloads import GenColumn
+for nkeys in ([10, 100000] if len(sys.argv) <= 4 else [int(x) for x in sys.argv[4].split(',')]):
+    ctx = E.Context(device=0, profile=True, tuning=TUNING)
+    cols = [GenColumn("k", DataType.DOUBLE, N.GEN_F64_MOD, 0, modulus=nkeys), GenColumn("v", DataType.DOUBLE, N.GEN_F64_UNIT, 1)]
+    b = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in cols], rows)
+    k, v = ColumnExpression("k", 0, DataType.DOUBLE), ColumnExpression("v", 1, DataType.DOUBLE)
+    args = ([ctx.compile(k)], [ctx.compile(v), ctx.compile(v)], [N.AGG_MIN, N.AGG_MAX])
+    r = E.filter_groupby(ctx, b, None, *args); ng = r.count; r.free()
+    ctx.reset_kernel_time()
+    for _ in range(5):
+        r = E.filter_groupby(ctx, b, None, *args); r.free()
+    _, tot, n = ctx.kernel_time()
+    ms = tot / n
+    print(f"GROUP BY DOUBLE k ({nkeys} distinct values), MIN(v), MAX(v): groups {ng} kernel {ms:.3f} ms "
+          f"{rows * 16 / ms / 1e6:.0f} GB/s = {rows * 16 / ms / 1e6 / 8000:.2f} of 8 TB/s ({rows / ms / 1e6:.1f} G rows/s)", flush=True)
+    b.free(); ctx.close()
