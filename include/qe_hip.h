@@ -181,6 +181,28 @@ int32_t qe_batch_column_to_host(qe_ctx *ctx, const qe_batch *batch, int32_t col,
                                 void *data_out, uint64_t *validity_out);
 void qe_batch_free(qe_ctx *ctx, qe_batch *batch);
 
+/* ---- CSV text -> columns ------------------------------------------------------------------
+ * The on-disk step in front of the path: replaces the row-at-a-time CSV scan leaves CsvTable / CsvSourceOperator
+ * (data/CsvTable.kt:12-29, operator/CsvSourceOperator.kt:52-76) and UnivocityCsvTable / UnivocityCsvScanOperator
+ * (data/UnivocityCsvTable.kt:10-69) beneath Table.getScanOperator (data/Table.kt:8).  Same conversion rules (first
+ * record = header, fields located by header name, empty lines skipped, missing or empty field = NULL, String.toBoolean,
+ * String.toDouble = java.lang.Double.parseDouble; a malformed number is QE_ERR_INVALID_ARG with the reference's
+ * NumberFormatException text), but the result is one contiguous array per projected field in the qe_col_desc layout
+ * (+ validity bitmap, + a dictionary in order of first appearance for STRING) that qe_csv_pin copies to HBM once.
+ * types[] may hold QE_STRING, QE_DOUBLE, QE_BOOLEAN (data/Schema.kt:3-5).  Host-side, needs no device. */
+typedef struct qe_csv_table qe_csv_table;
+int32_t qe_csv_parse(qe_ctx *ctx, const char *utf8, size_t nbytes, int32_t nfields, const char *const *names,
+                     const int32_t *types, qe_csv_table **out);
+int32_t qe_csv_parse_file(qe_ctx *ctx, const char *path, int32_t nfields, const char *const *names, const int32_t *types,
+                          qe_csv_table **out);
+int64_t qe_csv_nrows(const qe_csv_table *table);
+int32_t qe_csv_ncols(const qe_csv_table *table);
+/* host view of one parsed column (pointers owned by the table; validity == NULL: no NULL in the column) */
+int32_t qe_csv_column(const qe_csv_table *table, int32_t col, qe_col_desc *out);
+/* = qe_batch_create on the table's columns ("pin to HBM once"); the batch keeps the dictionaries alive */
+int32_t qe_csv_pin(qe_ctx *ctx, const qe_csv_table *table, qe_batch **out);
+void qe_csv_free(qe_ctx *ctx, qe_csv_table *table);
+
 /* ---- expressions ------------------------------------------------------------------ */
 /* compileExpression(expression, mode): evaluator/Compiler.kt:20-26 */
 int32_t qe_expr_compile(qe_ctx *ctx, const uint8_t *program, size_t len, qe_expr **out);

@@ -115,6 +115,84 @@ def read_csv_columns(path: str, schema: Schema, projection: Optional[Sequence[st
     return ColumnarTable(Schema(fields), cols)
 
 
+def read_csv_native(ctx, path_or_bytes, schema: Schema, projection: Optional[Sequence[str]] = None) -> ColumnarTable:
+    """The same conversion through the C ABI (qe_csv_parse / qe_csv_parse_file in libqe_hip.so: what a JVM host binds; a
+    planning-only context suffices -- parsing is host work).  Returns a ColumnarTable over copies of the parsed columns;
+    ``table.native`` keeps the qe_csv_table handle so that `pin_csv` can copy it to HBM without another conversion."""
+    import ctypes as C
+    from . import native as N
+    names = list(projection) if projection is not None else [f.name for f in schema.fields]
+    fields = []
+    for name in names:
+        f = schema[name]
+        if f is None:
+            raise RuntimeError(f"projected field {name} not found in schema")          # CsvSourceOperator.kt:25-26
+        fields.append(f)
+    lib = N.lib()
+    cnames = (C.c_char_p * max(1, len(fields)))(*[f.name.encode("utf-8") for f in fields])
+    ctypes_ = (C.c_int32 * max(1, len(fields)))(*[int(f.type) for f in fields])
+    h = C.c_void_p()
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        st = lib.qe_csv_parse(ctx.handle, bytes(path_or_bytes), len(path_or_bytes), len(fields), cnames, ctypes_, C.byref(h))
+    else:
+        st = lib.qe_csv_parse_file(ctx.handle, str(path_or_bytes).encode("utf-8"), len(fields), cnames, ctypes_, C.byref(h))
+    if st != 0:
+        msg = (lib.qe_last_error(ctx.handle) or b"").decode("utf-8", "replace")
+        if "not found in csv headers" in msg:
+            raise RuntimeError(msg)
+        if "NumberFormatException" in msg:
+            raise NumberFormatException(msg)
+        raise N.QeError(st, msg)
+    n = int(lib.qe_csv_nrows(h))
+    nwords = max(1, (n + 63) // 64)
+    cols = []
+    for j, f in enumerate(fields):
+        d = N.ColDesc()
+        N.check(ctx.handle, lib.qe_csv_column(h, j, C.byref(d)))
+        valid = None
+        if d.validity:
+            words = np.ctypeslib.as_array(C.cast(d.validity, C.POINTER(C.c_uint64)), shape=(nwords,)).copy()
+            valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(np.bool_)
+        if f.type == DataType.DOUBLE:
+            data = np.ctypeslib.as_array(C.cast(d.data, C.POINTER(C.c_double)), shape=(max(n, 1),))[:n].copy()
+            cols.append(Column(DataType.DOUBLE, data, valid))
+        elif f.type == DataType.BOOLEAN:
+            words = np.ctypeslib.as_array(C.cast(d.data, C.POINTER(C.c_uint64)), shape=(nwords,)).copy()
+            cols.append(Column(DataType.BOOLEAN, np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(np.bool_), valid))
+        else:
+            codes = np.ctypeslib.as_array(C.cast(d.data, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+            m = lib.qe_dict_size(d.dict)
+            dictionary = [lib.qe_dict_entry(d.dict, i).decode("utf-8") for i in range(m)]
+            cols.append(Column(DataType.STRING, codes, valid, dictionary))
+    t = ColumnarTable(Schema(fields), cols)
+    t.native = _NativeCsv(ctx, h)
+    return t
+
+
+class _NativeCsv:
+    """Owner of a qe_csv_table handle."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def pin(self):
+        """qe_csv_pin: the parsed columns -> HBM (one H2D per column), as an engine.DeviceBatch."""
+        import ctypes as C
+        from . import engine as E
+        from . import native as N
+        h = C.c_void_p()
+        N.check(self.ctx.handle, self.ctx._lib.qe_csv_pin(self.ctx.handle, self.handle, C.byref(h)))
+        return E.DeviceBatch(self.ctx, h)
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx._lib.qe_csv_free(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
 class CsvColumnarTable(ColumnarTable):
     """Drop-in for ``CsvTable(file, schema)`` (data/CsvTable.kt:12): parsed once, scanned columnar."""
 

@@ -84,6 +84,13 @@ SYMBOLS = [
     ("qe_batch_column_type", C.c_int32, [_P, C.c_int32]),
     ("qe_batch_column_to_host", C.c_int32, [_P, _P, C.c_int32, C.c_int64, C.c_int64, _P, _P]),
     ("qe_batch_free", None, [_P, _P]),
+    ("qe_csv_parse", C.c_int32, [_P, C.c_char_p, C.c_size_t, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(_P)]),
+    ("qe_csv_parse_file", C.c_int32, [_P, C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(_P)]),
+    ("qe_csv_nrows", C.c_int64, [_P]),
+    ("qe_csv_ncols", C.c_int32, [_P]),
+    ("qe_csv_column", C.c_int32, [_P, C.c_int32, C.POINTER(ColDesc)]),
+    ("qe_csv_pin", C.c_int32, [_P, _P, C.POINTER(_P)]),
+    ("qe_csv_free", None, [_P, _P]),
     ("qe_expr_compile", C.c_int32, [_P, C.c_char_p, C.c_size_t, C.POINTER(_P)]),
     ("qe_expr_result_type", C.c_int32, [_P]),
     ("qe_expr_free", None, [_P, _P]),

@@ -54,6 +54,75 @@ def test_csv_rules(tmp_path):
         read_csv_columns(str(p), Schema([Field("missing", S)]), ["missing"])
 
 
+def test_native_csv_parser_matches_the_python_restatement(tmp_path, native_lib):
+    """qe_csv_parse / qe_csv_parse_file (C ABI, what the JVM host binds) against the Python restatement of the same rules on
+    the fixture above and on quoting / line-end / Unicode edge cases; a planning-only context suffices (host work)."""
+    from queryengine_amd import engine as E
+    from queryengine_amd.csv_table import read_csv_native
+    ctx = E.Context(device=None, jit_cache_dir=str(tmp_path / "jit"))
+    schema = Schema([Field("id", S), Field("country", S), Field("price", D), Field("paid", B), Field("note", S)])
+    more = ("id,country,price,paid,note\r\n"                      # CRLF line ends
+            '7,"multi\nline",1e-3,true,"a,b"\r\n'
+            "\r\n"
+            '8,Z\u00fcrich \U0001F600,+.5,tRuE,""\r'              # a lone CR ends a record too; quoted empty string = NULL
+            "9,,Infinity,,last")                                  # no line end after the last record
+    for k, text in enumerate((CSV, more)):
+        p = tmp_path / f"t{k}.csv"
+        p.write_bytes(text.encode("utf-8"))
+        for proj in (None, ["price", "id"], ["note", "paid", "country"]):
+            want = read_csv_columns(str(p), schema, proj)
+            for src in (str(p), text.encode("utf-8")):
+                got = read_csv_native(ctx, src, schema, proj)
+                assert got.nrows == want.nrows and [f.name for f in got.schema.fields] == [f.name for f in want.schema.fields]
+                for g, w in zip(got.columns, want.columns):
+                    assert g.type == w.type and g.dictionary == w.dictionary
+                    gv = g.valid if g.valid is not None else np.ones(len(g), bool)
+                    wv = w.valid if w.valid is not None else np.ones(len(w), bool)
+                    assert np.array_equal(gv, wv)
+                    if g.type == D:
+                        assert np.array_equal(g.data[gv].view(np.uint64), w.data[wv].view(np.uint64))
+                    else:
+                        assert np.array_equal(g.data[gv], w.data[wv])
+    t = read_csv_native(ctx, more.encode("utf-8"), schema)
+    assert t.column("country").to_list() == ["multi\nline", "Z\u00fcrich \U0001F600", None]
+    assert t.column("note").to_list() == ["a,b", None, "last"] and t.column("price").to_list() == [0.001, 0.5, float("inf")]
+    # errors speak the reference's language
+    with pytest.raises(RuntimeError):
+        read_csv_native(ctx, CSV.encode(), Schema([Field("missing", S)]))
+    with pytest.raises(RuntimeError):       # a byte order mark stays part of the first header name (FileReader(file, UTF_8))
+        read_csv_native(ctx, ("\ufeff" + CSV).encode("utf-8"), schema, ["id"])
+    for bad in ("1_0", "inf", "nan", "0x10", "1e", "abc", "1,5"):
+        with pytest.raises(NumberFormatException):
+            read_csv_native(ctx, f'price\n"{bad}"\n'.encode(), Schema([Field("price", D)]))
+    ok = read_csv_native(ctx, b"price\n 0x1.8p1 \n7D\n-NaN\n1e400\n", Schema([Field("price", D)])).columns[0].data
+    assert ok[0] == 3.0 and ok[1] == 7.0 and math.isnan(ok[2]) and ok[3] == float("inf")
+    with pytest.raises(Exception):
+        read_csv_native(ctx, b'a\n"unterminated\n', Schema([Field("a", S)]))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_native_csv_table_pinned_and_queried(tmp_path, gpu_ctx, oracle):
+    """qe_csv_parse_file -> qe_csv_pin -> qe_filter_project: the CSV scan leaf through the C ABI end to end."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    from queryengine_amd.csv_table import read_csv_native
+    p = tmp_path / "orders.csv"
+    p.write_text(CSV, encoding="utf-8")
+    schema = Schema([Field("id", S), Field("country", S), Field("price", D), Field("paid", B), Field("note", S)])
+    t = read_csv_native(gpu_ctx, str(p), schema)
+    batch = t.native.pin()
+    assert batch.nrows == 6 and batch.ncols == 5
+    price, paid, country = ColumnExpression("price", 2, D), ColumnExpression("paid", 3, B), ColumnExpression("country", 1, S)
+    flt = FunctionExpression(Function.AND, [paid, FunctionExpression(Function.CMP_LT, [price, NumericLiteralExpression(1000.0)], B)], B)
+    projs = [country, FunctionExpression(Function.MUL, [price, NumericLiteralExpression(2.0)], D)]
+    res = E.filter_project(gpu_ctx, batch, gpu_ctx.compile(flt), [gpu_ctx.compile(e) for e in projs])
+    got = res.to_columns()
+    want = oracle.filter_project(t.columns, flt, projs, oracle.BYTECODE_COMPILER)
+    assert got[0].to_list() == want[0].to_list() == ["DE", "AT"] and got[1].to_list() == want[1].to_list() == [201.0, 50.0]
+    res.free(); batch.free()
+
+
 @pytest.mark.gpu
 def test_query_over_csv_table(tmp_path, gpu_ctx):
     from queryengine_amd.planner import Mode, query
