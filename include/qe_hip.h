@@ -270,6 +270,11 @@ void qe_result_free(qe_ctx *ctx, qe_result *result);
  * reference's single Operator (operator/Operators.kt:5-11) the whole result.  Parts must share schema and dictionaries. */
 int32_t qe_result_concat(qe_ctx *ctx, const qe_result *const *parts, int32_t nparts, qe_result **out);
 
+/* ORDER BY <column> of a materialised result, on the device: OrderByOperator.open (operator/OrderByOperator.kt:9-15) sorts
+ * the rows STABLY with Kotlin's compareValues -- NULL first, Double.compareTo (-0.0 < 0.0, NaN greatest), String.compareTo
+ * (UTF-16 code units), false < true.  `column` is 0-based (the planner's ORDER BY <ordinal> is 1-based: Planner.kt:60). */
+int32_t qe_result_order_by(qe_ctx *ctx, const qe_result *result, int32_t column, qe_result **out);
+
 /* ---- the exchange step of a row-range sharded scan -------------------------------------------------------
  * One process (one qe_ctx) per GPU; rank r scans rows [r*N/P, (r+1)*N/P) with NO communication.  Only a plan whose root
  * materialises its result on one rank (evaluator/Planner.kt:30-63: ONE Operator yields the whole result; Main.kt:18

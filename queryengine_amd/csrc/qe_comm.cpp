@@ -281,6 +281,77 @@ int32_t qe_result_concat(qe_ctx *ctx, const qe_result *const *parts, int32_t npa
     });
 }
 
+// ORDER BY <column> on the device: OrderByOperator.open (operator/OrderByOperator.kt:9-15) sorts the materialised rows stably
+// with compareValues -- null first, Double.compareTo (-0.0 < 0.0, NaN greatest), String.compareTo (UTF-16 code units),
+// false < true.  Key images + stable LSD radix sort of (key, row id) + gather of every column (qe_sort.hip).
+int32_t qe_result_order_by(qe_ctx *ctx, const qe_result *src, int32_t column, qe_result **out) {
+    if (!ctx || !src || !out || column < 0 || column >= (int32_t)src->cols.size()) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        const int64_t n = src->count;
+        if (n >= (1ll << 32)) fail(QE_ERR_UNSUPPORTED, "qe_result_order_by: more than 2^32 rows");
+        uint32_t any_validity = 0;
+        for (size_t c = 0; c < src->cols.size(); c++)
+            if (src->cols[c].validity) any_validity |= 1u << c;
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(make_output(ctx, src, n, any_validity),
+                                                                          [ctx](qe_result *r) { free_output(ctx, r); });
+        if (n > 0) {
+            Scratch sc{ctx, {}};
+            const OutColumn &kc = src->cols[(size_t)column];
+            unsigned long long *keys[2] = {(unsigned long long *)sc.get((size_t)n * 8), (unsigned long long *)sc.get((size_t)n * 8)};
+            uint32_t *rows[2] = {(uint32_t *)sc.get((size_t)n * 4), (uint32_t *)sc.get((size_t)n * 4)};
+            uint32_t *hist = (uint32_t *)sc.get((size_t)((n + 1023) / 1024) * 16 * 4);
+            SortKeyArgs ka{};
+            ka.type = kc.type;
+            ka.data = kc.data;
+            ka.validity = (const unsigned long long *)kc.validity;
+            ka.n = n;
+            ka.keys = keys[0];
+            ka.rows = rows[0];
+            if (kc.type == QE_STRING) {   // String.compareTo order of the dictionary (UTF-16 code units), as dense ranks
+                if (!kc.dict) fail(QE_ERR_INVALID_ARG, "STRING column without dictionary");
+                const std::vector<std::vector<int32_t>> ranks = merged_ranks({&kc.dict->entries});
+                int *d_ranks = (int *)sc.get(std::max<size_t>(ranks[0].size() * 4, 16));
+                if (!ranks[0].empty()) QE_HIP(hipMemcpyAsync(d_ranks, ranks[0].data(), ranks[0].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                QE_HIP(hipStreamSynchronize(ctx->stream));   // `ranks` is a host temporary
+                ka.ranks = d_ranks;
+                ka.nranks = (int)ranks[0].size();
+            }
+            launch_sort_keys(ctx->stream, ka);
+            // which digits differ at all?
+            unsigned long long *d_bits = (unsigned long long *)sc.get(16);
+            const unsigned long long init[2] = {0ull, ~0ull};
+            QE_HIP(hipMemcpyAsync(d_bits, init, 16, hipMemcpyHostToDevice, ctx->stream));
+            launch_key_bits(ctx->stream, keys[0], n, d_bits);
+            unsigned long long h_bits[2] = {0, 0};
+            QE_HIP(hipMemcpyAsync(h_bits, d_bits, 16, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            const unsigned long long varying = h_bits[0] & ~h_bits[1];
+            int cur = 0;
+            for (int shift = 0; shift < 64; shift += 4) {
+                if (((varying >> shift) & 15ull) == 0) continue;   // the same digit in every key
+                launch_radix_pass(ctx->stream, keys[cur], rows[cur], nullptr, n, shift, hist, keys[cur ^ 1], rows[cur ^ 1]);
+                cur ^= 1;
+            }
+            if (kc.validity) {   // NULL rows in front (compareValues), in their input order
+                launch_radix_pass(ctx->stream, keys[cur], rows[cur], kc.validity, n, 64, hist, keys[cur ^ 1], rows[cur ^ 1]);
+                cur ^= 1;
+            }
+            for (size_t c = 0; c < src->cols.size(); c++) {
+                const OutColumn &s_ = src->cols[c];
+                OutColumn &d_ = res->cols[c];
+                if (s_.type == QE_BOOLEAN) launch_gather_bits_rows(ctx->stream, (const uint64_t *)s_.data, rows[cur], n, (uint64_t *)d_.data);
+                else launch_gather_rows(ctx->stream, (int)width_of(s_.type), s_.data, rows[cur], n, d_.data);
+                if (d_.nullable) launch_gather_bits_rows(ctx->stream, s_.validity, rows[cur], n, d_.validity);
+            }
+            QE_HIP(hipGetLastError());
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        *out = res.release();
+    });
+}
+
 // Materialise a sharded result on rank `root`: *out is the concatenation in rank order there, NULL elsewhere.
 // Collective: every rank of the communicator calls it with its local result (same plan => same column types).
 int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out) {

@@ -46,6 +46,28 @@ void launch_ht_init(hipStream_t s, unsigned long long *tab, int64_t nentries, co
 void launch_ht_collect(hipStream_t s, const unsigned long long *tab, int64_t nentries, int words, unsigned long long *dense,
                        unsigned int *counter);
 
+// ---- ORDER BY (qe_sort.hip) ----
+// keys[i] = order-preserving u64 image of row i of the key column (0 under a NULL), rows[i] = i
+struct SortKeyArgs {
+    int type;                       // QE_* of the key column
+    const void *data;
+    const unsigned long long *validity;
+    const int *ranks;               // QE_STRING: compareTo rank per dictionary code
+    int nranks;
+    long long n;
+    unsigned long long *keys;
+    unsigned int *rows;
+};
+void launch_sort_keys(hipStream_t s, const SortKeyArgs &a);
+// or_and[0] |= every key, or_and[1] &= every key (caller initialises to {0, ~0})
+void launch_key_bits(hipStream_t s, const unsigned long long *keys, int64_t n, unsigned long long *or_and);
+// one stable LSD radix pass over the 4 key bits at `shift` (shift == 64: over the validity bit of each element's row, NULL
+// first); hist: 16 * ceil(n / 1024) u32 of scratch
+void launch_radix_pass(hipStream_t s, const unsigned long long *keys, const uint32_t *rows, const uint64_t *validity, int64_t n, int shift,
+                       uint32_t *hist, unsigned long long *keys_out, uint32_t *rows_out);
+void launch_gather_rows(hipStream_t s, int width, const void *src, const uint32_t *rows, int64_t n, void *out);
+void launch_gather_bits_rows(hipStream_t s, const uint64_t *src, const uint32_t *rows, int64_t n, uint64_t *out);
+
 // place nbits bits of src at bit offset dst_bit_offset of dst (bitmap words; concatenation of results / gather)
 void launch_bitmap_place(hipStream_t s, uint64_t *dst, int64_t dst_bit_offset, const uint64_t *src, int64_t nbits);
 

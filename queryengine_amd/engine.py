@@ -133,6 +133,12 @@ class Context:
         N.check(self.handle, self._lib.qe_comm_allgather_host(self.handle, payload, len(payload), recv))
         return [recv.raw[i * len(payload):(i + 1) * len(payload)] for i in range(n)]
 
+    def order_by(self, result: "Result", column: int) -> "Result":
+        """qe_result_order_by: the rows of `result` sorted stably by `column` (0-based) with compareValues order."""
+        h = C.c_void_p()
+        N.check(self.handle, self._lib.qe_result_order_by(self.handle, result.handle, column, C.byref(h)))
+        return Result(self, h)
+
     def concat(self, parts: Sequence["Result"]) -> "Result":
         """qe_result_concat: results of this device, concatenated in the given order."""
         arr = (C.c_void_p * max(1, len(parts)))(*[p.handle for p in parts])

@@ -107,6 +107,7 @@ SYMBOLS = [
     ("qe_result_column_to_host", C.c_int32, [_P, _P, C.c_int32, _P, _P]),
     ("qe_result_free", None, [_P, _P]),
     ("qe_result_concat", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(_P)]),
+    ("qe_result_order_by", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
     ("qe_comm_unique_id", C.c_int32, [_P, _P]),
     ("qe_comm_init", C.c_int32, [_P, C.c_int32, C.c_int32, _P]),
     ("qe_comm_rank", C.c_int32, [_P]),

@@ -79,21 +79,37 @@ def _compare_key(value: Any):
 class OrderByOperator(Operator):
     """operator/OrderByOperator.kt:5-31: drain the source in ``open()``, stable ``sortBy`` on one column.
 
-    A host-side consumer of the path's output (sorting is not on the filter/project path); the rows
-    it sorts were produced by the GPU operators below it."""
+    A consumer of the path's output.  When the source is a GPU operator whose result sits in HBM
+    (``result()``), the rows are sorted there (qe_result_order_by: key images, stable radix sort, gather) and boxed
+    afterwards; any other source is drained and sorted on the host with the same ``compareValues`` order."""
 
     def __init__(self, source: Operator, index: int):
         self.source = source
         self.index = index
         self._iter = None
+        self._sorted: Optional[E.Result] = None
 
     def open(self) -> None:
+        if hasattr(self.source, "result") and hasattr(self.source, "ctx"):
+            self.source.open()
+            try:
+                res = self.source.result()
+                self._sorted = self.source.ctx.order_by(res, self.index)
+            finally:
+                self.source.close()
+            cols = self._sorted.to_columns()
+            n = self._sorted.count
+            self._iter = ([c.value(i) for c in cols] for i in range(n))
+            return
         data = mapTo(self.source, [], lambda row: list(row))
         data.sort(key=lambda row: _compare_key(row[self.index]))   # list.sort is stable, like java.util.List.sort
         self._iter = iter(data)
 
     def close(self) -> None:
         self._iter = None
+        if self._sorted is not None:
+            self._sorted.free()
+            self._sorted = None
 
     def next(self) -> Optional[List[Any]]:
         if self._iter is None:

@@ -357,3 +357,63 @@ def test_tripdata_query_shape_group_by_double_column(gpu_ctx):
     for key, lo, hi in rows:
         sel = fare[pc == key]
         assert lo == sel.min() and hi == sel.max()
+
+
+@pytest.mark.parametrize("keytype", ["double", "int64", "string", "boolean", "int32"])
+def test_order_by_on_the_device_matches_compare_values(gpu_ctx, keytype):
+    """qe_result_order_by: OrderByOperator.kt:9-12 -- stable sortBy { row[index] as Comparable } = compareValues: null first,
+    Double.compareTo (-0.0 < 0.0, NaN last), String.compareTo (UTF-16 code units), false < true; every other column
+    follows its row; ties keep their input order (200 k rows, many ties, nullable key and payload)."""
+    from queryengine_amd import ColumnExpression
+    from queryengine_amd import engine as E
+    from queryengine_amd.operators import _compare_key
+    rng = np.random.default_rng(9)
+    n = 200_003
+    if keytype == "double":
+        pool = np.array([0.0, -0.0, 1.5, -1.5, float("nan"), float("inf"), -float("inf"), 1e300, -1e-300, 3.0])
+        key = Column(D, np.where(rng.random(n) < 0.5, pool[rng.integers(0, len(pool), n)], rng.normal(0, 1e3, n)), rng.random(n) > 0.05)
+    elif keytype == "int64":
+        pool = np.array([0, -1, 1, 2 ** 63 - 1, -(2 ** 63), 2 ** 53 + 1, 2 ** 63 - 2], dtype=np.int64)
+        key = Column(I64, np.where(rng.random(n) < 0.3, pool[rng.integers(0, len(pool), n)], rng.integers(-50, 50, n)), rng.random(n) > 0.05)
+    elif keytype == "int32":
+        key = Column(I32, rng.integers(-2 ** 31, 2 ** 31 - 1, n).astype(np.int32) // (1 << 20), rng.random(n) > 0.05)
+    elif keytype == "string":
+        d = ["b", "a", "", "B", "\uff5e", "\U0001F600", "aa", "Z\u00fc", "zz", "a\u0000"]
+        key = Column(S, rng.integers(0, len(d), n).astype(np.int32), rng.random(n) > 0.05, d)
+    else:
+        key = Column(B, rng.random(n) > 0.5, rng.random(n) > 0.1)
+    rowid = Column(I64, np.arange(n, dtype=np.int64))
+    flag = Column(B, rng.random(n) > 0.3, rng.random(n) > 0.2)
+    batch = E.DeviceBatch.from_columns(gpu_ctx, [key, rowid, flag])
+    projs = [gpu_ctx.compile(ColumnExpression("k", 0, key.type)), gpu_ctx.compile(ColumnExpression("r", 1, I64)),
+             gpu_ctx.compile(ColumnExpression("f", 2, B))]
+    res = E.filter_project(gpu_ctx, batch, None, projs)
+    srt = gpu_ctx.order_by(res, 0)
+    k, r, f = srt.to_columns()
+    want = sorted(range(n), key=lambda i: _compare_key(key.value(i)))          # stable, like java.util.List.sort
+    assert np.array_equal(r.data, np.array(want, dtype=np.int64))
+    for j in (0, 1, n // 3, n // 2, n - 2, n - 1):
+        i = want[j]
+        a, b = k.value(j), key.value(i)
+        assert (a == b) or (a != a and b != b)
+        assert f.value(j) == flag.value(i)
+    res.free(); srt.free(); batch.free()
+
+
+def test_order_by_query_sorts_on_the_device(gpu_ctx):
+    """Main.kt:35-50 shape through query(): the OrderByOperator above a GPU operator sorts its result in HBM."""
+    from queryengine_amd.planner import Mode, query
+    rng = np.random.default_rng(4)
+    n = 30_000
+    a = rng.integers(0, 1000, n).astype(np.float64)
+    c = rng.random(n)
+    t = ColumnarTable(Schema([Field("a", D), Field("c", D)]), [Column(D, a), Column(D, c, rng.random(n) > 0.1)])
+    reg = TableRegistry()
+    reg.register("t", t)
+    rows = query(reg, "SELECT a + 1, c FROM t WHERE a < 500 ORDER BY 2", Mode.GPU_FUSED, ctx=gpu_ctx)
+    keep = a < 500
+    cv = t.columns[1]
+    exp = [[a[i] + 1, cv.value(i)] for i in np.nonzero(keep)[0]]
+    from queryengine_amd.operators import _compare_key
+    exp.sort(key=lambda r: _compare_key(r[1]))
+    assert rows == exp and rows[0][1] is None
