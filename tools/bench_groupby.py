@@ -8,7 +8,7 @@ from queryengine_amd.datatypes import DataType
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 KEYS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [10, 1000, 100000]
-TUNING = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else []
+TUNING = [int(x) for x in sys.argv[3].split(',') if x] if len(sys.argv) > 3 else []
 for nkeys in KEYS:
     wl = W.config4(rows, nkeys=nkeys)
     ctx = E.Context(device=0, profile=True, tuning=TUNING)
