@@ -16,6 +16,8 @@ interface ColumnarSource {
     /** off-heap column buffers in the layouts of qe_col_desc */
     fun columnDescs(arena: Arena): MemorySegment
     val columnCount: Int
+    /** a source that already holds its columns in HBM (GpuCsvTable: qe_csv_pin) hands the qe_batch* over; default: none */
+    fun deviceBatch(ctx: MemorySegment): MemorySegment = MemorySegment.NULL
 }
 
 class GpuFilterProjectOperator(
@@ -45,6 +47,7 @@ class GpuFilterProjectOperator(
     }
 
     override fun open() {
+        if (batch == MemorySegment.NULL) batch = source.deviceBatch(ctx)
         if (batch == MemorySegment.NULL) {
             val out = arena.allocate(ADDRESS)
             QeNative.check(ctx, QeNative.qe_batch_create.invokeExact(ctx, source.rowCount, source.columnCount,
@@ -58,6 +61,9 @@ class GpuFilterProjectOperator(
         columns = null
         idx = 0
     }
+
+    /** the qe_result* of the last open(): for a downstream GPU consumer (qe_gather, qe_result_order_by) */
+    fun result(): MemorySegment = result.also { check(it != MemorySegment.NULL) { "Operator not initialized" } }
 
     override fun next(): Array<Any?>? {
         check(result != MemorySegment.NULL) { "Operator not initialized" }

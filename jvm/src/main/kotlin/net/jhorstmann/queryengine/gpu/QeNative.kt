@@ -39,6 +39,30 @@ internal object QeNative {
     val qe_result_column = handle("qe_result_column", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS)
     val qe_result_column_to_host = handle("qe_result_column_to_host", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS)
     val qe_result_free = handle("qe_result_free", null, ADDRESS, ADDRESS)
+    // ctx, qe_result*[nparts], nparts, qe_result** -> status: results of consecutive batches as ONE result (input order)
+    val qe_result_concat = handle("qe_result_concat", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS)
+    // ctx, result, column (0-based), qe_result** -> status: OrderByOperator.kt:9-15 on the device
+    val qe_result_order_by = handle("qe_result_order_by", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS)
+
+    // ---- the exchange step of a row-range sharded scan: one JVM process (one qe_ctx) per GPU ----
+    // rank 0: qe_comm_unique_id(ctx, id128) -> the 128 bytes travel to the other ranks over the host's own channel
+    val qe_comm_unique_id = handle("qe_comm_unique_id", JAVA_INT, ADDRESS, ADDRESS)
+    val qe_comm_init = handle("qe_comm_init", JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS)       // ctx, nranks, rank, id128
+    val qe_comm_rank = handle("qe_comm_rank", JAVA_INT, ADDRESS)
+    val qe_comm_nranks = handle("qe_comm_nranks", JAVA_INT, ADDRESS)
+    val qe_comm_destroy = handle("qe_comm_destroy", null, ADDRESS)
+    // collective: ctx, local result, root, qe_result** (non-NULL on root only) -> status (QE_ERR_COMM = 7 on an RCCL failure)
+    val qe_gather = handle("qe_gather", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS)
+    // collective: ctx, send, nbytes, recv[nranks * nbytes] (host buffers): aggregate partials, counts
+    val qe_comm_allgather_host = handle("qe_comm_allgather_host", JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS)
+
+    // ---- CSV text -> columns (replaces CsvTable / UnivocityCsvTable scan leaves) ----
+    // ctx, path, nfields, char*[names], int32[types], qe_csv_table** -> status
+    val qe_csv_parse_file = handle("qe_csv_parse_file", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS)
+    val qe_csv_nrows = handle("qe_csv_nrows", JAVA_LONG, ADDRESS)
+    val qe_csv_column = handle("qe_csv_column", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS)                  // -> qe_col_desc (host pointers)
+    val qe_csv_pin = handle("qe_csv_pin", JAVA_INT, ADDRESS, ADDRESS, ADDRESS)                          // -> qe_batch (HBM)
+    val qe_csv_free = handle("qe_csv_free", null, ADDRESS, ADDRESS)
 
     /** struct qe_col_desc { int32 type; int32 reserved; const void* data; const uint64* validity; const qe_dict* dict; } */
     val COL_DESC: StructLayout = MemoryLayout.structLayout(
