@@ -3,11 +3,16 @@
 // The on-device analogue of Mode.INTERPRETER's tree walk (evaluator/Interpreter.kt:29-109): every
 // node of the typed tree becomes one launch of a precompiled kernel (qe_pernode_kernels.hip) over
 // whole columns; BOOLEAN values and validity travel as 64-row bitmap words.  The executor is
-// filter-first (late materialisation):
-//   1. evaluate the Filter's nodes over the full batch -> (value, known) bitmaps
-//   2. keep = value & known (FilterOperator.kt:20) -> word popcounts -> scan -> ascending row ids
-//   3. gather only the columns the projections reference at those row ids
-//   4. evaluate the Projection's nodes over the compacted columns
+// filter-first, conjunct by conjunct (late materialisation at node granularity):
+//   1. the Filter's top-level AND chain is split into its conjuncts (FilterOperator keeps a row iff the predicate is a
+//      non-null TRUE, FilterOperator.kt:20, and a Kleene AND is TRUE iff every operand is: the keep mask of the chain is the
+//      AND of the conjuncts' keep masks; the reference's AND is lazy in the same direction, Interpreter.kt:54-72)
+//   2. a conjunct is evaluated over the CURRENT domain -> keep = value & known -> word popcounts -> scan; when at most half
+//      of the domain survives (or it is the last conjunct) the domain is narrowed to the kept rows: ascending row ids,
+//      columns already gathered are re-gathered from their compact copies
+//   3. a column is gathered from the batch only when a node first needs it in a narrowed domain -- at that domain's
+//      density: cfg 2 reads `a` in full, `c` where a < 100 and `b` (and `a` again) only for the rows finally kept
+//   4. the Projection's nodes are evaluated over the final domain
 // It needs no JIT and is the general path; the fused kernel (qe_codegen.cpp) is the fast path.
 #include "qe_pernode.h"
 
@@ -43,8 +48,101 @@ struct Exec {
     qe_ctx *ctx;
     hipStream_t s;
     int64_t n = 0;               // rows of the current domain
-    std::vector<Vec> env;        // batch columns of the current domain
+    std::vector<Vec> base;       // the batch's columns (full domain)
+    std::vector<Vec> env;        // columns of the current domain; data == null: not gathered for it yet
+    Buf ids;                     // u32 batch row ids of the current domain's rows (null: the domain is the whole batch)
     int ieee;
+
+    // column j in the current domain: gathered from the batch when a node first needs it here
+    const Vec &column(int j) {
+        const Vec &b = base[(size_t)j];
+        if (!ids) return b;          // whole batch: the column itself (never cached: narrowing would re-gather it for nothing)
+        Vec &v = env[(size_t)j];
+        if (v.data) return v;
+        v.type = b.type;
+        v.dict = b.dict;
+        if (b.type == QE_BOOLEAN) {
+            v.data = alloc_words();
+            pn::gather_bits(s, (const uint64_t *)b.data.get(), (const uint32_t *)ids.get(), (uint64_t *)v.data.get(), n);
+        } else {
+            v.data = alloc_col(b.type);
+            pn::GatherArgs ga{};
+            ga.idx = (const uint32_t *)ids.get();
+            ga.m = n;
+            ga.src[0] = b.data.get();
+            ga.dst[0] = v.data.get();
+            ga.width[0] = (int)width_of(b.type);
+            ga.ncols = 1;
+            pn::gather_multi(s, ga);
+        }
+        if (b.valid) {
+            v.valid = alloc_words();
+            pn::gather_bits(s, (const uint64_t *)b.valid.get(), (const uint32_t *)ids.get(), (uint64_t *)v.valid.get(), n);
+        }
+        return v;
+    }
+
+    // the value columns in `cols` that the current (narrowed) domain has not gathered yet: ONE launch, the ids are read once
+    void prefetch(const std::vector<char> &cols) {
+        if (!ids || n <= 0) return;
+        pn::GatherArgs ga{};
+        ga.idx = (const uint32_t *)ids.get();
+        ga.m = n;
+        auto flush = [&]() {
+            if (ga.ncols > 0) pn::gather_multi(s, ga);
+            ga.ncols = 0;
+        };
+        for (size_t j = 0; j < env.size(); j++) {
+            if (!cols[j] || env[j].data || base[j].type == QE_BOOLEAN) continue;
+            Vec &v = env[j];
+            v.type = base[j].type;
+            v.dict = base[j].dict;
+            v.data = alloc_col(base[j].type);
+            ga.src[ga.ncols] = base[j].data.get();
+            ga.dst[ga.ncols] = v.data.get();
+            ga.width[ga.ncols] = (int)width_of(base[j].type);
+            if (++ga.ncols == 8) flush();
+            if (base[j].valid) {
+                v.valid = alloc_words();
+                pn::gather_bits(s, (const uint64_t *)base[j].valid.get(), (const uint32_t *)ids.get(), (uint64_t *)v.valid.get(), n);
+            }
+        }
+        flush();
+    }
+
+    // narrow the domain to its rows rel[0..m) (ascending positions inside the current domain)
+    void narrow(const Buf &rel, int64_t m) {
+        const uint32_t *r = (const uint32_t *)rel.get();
+        const int64_t old_n = n;
+        (void)old_n;
+        n = m;
+        if (ids) {
+            Buf nids = alloc((size_t)std::max<int64_t>(m, 1) * 4);
+            pn::gather(s, QE_INT32, ids.get(), r, nids.get(), m);
+            ids = nids;
+        } else {
+            ids = rel;
+        }
+        for (size_t j = 0; j < env.size(); j++) {
+            Vec &v = env[j];
+            if (!v.data) continue;           // never needed so far: gathered from the batch if a later node asks for it
+            Vec c;
+            c.type = v.type;
+            c.dict = v.dict;
+            if (v.type == QE_BOOLEAN) {
+                c.data = alloc_words();
+                pn::gather_bits(s, (const uint64_t *)v.data.get(), r, (uint64_t *)c.data.get(), m);
+            } else {
+                c.data = alloc_col(v.type);
+                pn::gather(s, kernel_type(v.type), v.data.get(), r, c.data.get(), m);
+            }
+            if (v.valid) {
+                c.valid = alloc_words();
+                pn::gather_bits(s, (const uint64_t *)v.valid.get(), r, (uint64_t *)c.valid.get(), m);
+            }
+            v = c;
+        }
+    }
 
     Buf alloc(size_t bytes) {
         void *p = ctx->pool.alloc(std::max<size_t>(bytes, 16));
@@ -111,11 +209,11 @@ struct Exec {
         r.type = nd.type;
         switch (nd.kind) {
         case N_COLUMN: {
-            if (nd.col < 0 || nd.col >= (int)env.size()) fail(QE_ERR_PROGRAM, "column index out of range");
-            if (env[nd.col].type != nd.type)
-                fail(QE_ERR_PROGRAM, std::string("column ") + std::to_string(nd.col) + " is " + type_name(env[nd.col].type) +
+            if (nd.col < 0 || nd.col >= (int)base.size()) fail(QE_ERR_PROGRAM, "column index out of range");
+            if (base[nd.col].type != nd.type)
+                fail(QE_ERR_PROGRAM, std::string("column ") + std::to_string(nd.col) + " is " + type_name(base[nd.col].type) +
                                          " in the batch but " + type_name(nd.type) + " in the expression");
-            return env[nd.col];
+            return column(nd.col);
         }
         case N_NUM: r.scalar = true; r.f = nd.num; return r;
         case N_BOOL: r.scalar = true; r.i = nd.bval ? 1 : 0; return r;
@@ -341,7 +439,11 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         v.data = Buf(c.data, [](void *) {});
         if (c.validity) v.valid = Buf(c.validity, [](void *) {});
         v.dict = c.dict;
-        x.env.push_back(v);
+        x.base.push_back(v);
+        Vec e;
+        e.type = c.type;
+        e.dict = c.dict;
+        x.env.push_back(e);          // not gathered yet
     }
     std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) {
         for (auto &c : r->cols) {
@@ -351,67 +453,49 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         delete r;
     });
     int64_t m = batch->nrows;
+    if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (filter && batch->nrows > 0) {
         const Expr &fe = filter->e;
         if (fe.nodes[fe.root].type != QE_BOOLEAN) fail(QE_ERR_PROGRAM, "filter expression must be BOOLEAN");
-        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        Vec keep = x.materialize(x.eval(fe, fe.root));
-        // 2. selection vector
-        const int64_t nw = words_of(x.n);
-        Buf counts = x.alloc((size_t)nw * 4), offsets = x.alloc((size_t)nw * 4), sums = x.alloc((size_t)((nw + 1023) / 1024) * 4 + 16);
-        pn::word_popcounts(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
-                           (uint32_t *)counts.get(), nw);
+        // 1. the conjuncts of the top-level AND chain, left to right
+        std::vector<int> conj;
+        std::function<void(int)> split = [&](int id) {
+            const Node &nd = fe.nodes[id];
+            if (nd.kind == N_FN && nd.fn == QE_FN_AND && nd.ops.size() == 2) { split(nd.ops[0]); split(nd.ops[1]); }
+            else conj.push_back(id);
+        };
+        split(fe.root);
         unsigned long long *d_total = (unsigned long long *)(ctx->d_ctrl + 2);
-        pn::exclusive_scan_u32(x.s, (const uint32_t *)counts.get(), (uint32_t *)offsets.get(), (uint32_t *)sums.get(), nw, d_total);
-        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, x.s));
-        QE_HIP(hipGetLastError());
-        QE_HIP(hipStreamSynchronize(x.s));
-        m = (int64_t)ctx->h_ctrl[1];
-        if (ctx->opts.result_capacity_rows > 0 && m > ctx->opts.result_capacity_rows)   // same contract as the fused path
-            fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(m) + " rows but result_capacity_rows is " +
-                                         std::to_string(ctx->opts.result_capacity_rows));
-        // 3. gather the referenced columns at the kept row ids: value columns in one launch per 8 columns (the ids are read
-        //    once), bitmap columns (BOOLEAN values, validity) bit by bit
-        Buf idx = x.alloc((size_t)std::max<int64_t>(m, 1) * 4);
-        pn::expand_indices(x.s, (const uint64_t *)keep.data.get(), (const uint64_t *)keep.valid.get(), x.n,
-                           (const uint32_t *)offsets.get(), (uint32_t *)idx.get(), nw);
+        Buf acc;   // keep mask accumulated over the conjuncts evaluated in the current domain since it was last narrowed
+        for (size_t ci = 0; ci < conj.size() && x.n > 0; ci++) {
+            const bool last = ci + 1 == conj.size();
+            Vec k = x.materialize(x.eval(fe, conj[ci]));
+            Buf keep = x.and_valid(k.data, k.valid);              // value & known (FilterOperator.kt:20)
+            acc = x.and_valid(acc, keep);
+            // 2. kept rows of the current domain
+            const int64_t nw = words_of(x.n);
+            Buf counts = x.alloc((size_t)nw * 4), offsets = x.alloc((size_t)nw * 4), sums = x.alloc((size_t)((nw + 1023) / 1024) * 4 + 16);
+            pn::word_popcounts(x.s, (const uint64_t *)acc.get(), nullptr, x.n, (uint32_t *)counts.get(), nw);
+            pn::exclusive_scan_u32(x.s, (const uint32_t *)counts.get(), (uint32_t *)offsets.get(), (uint32_t *)sums.get(), nw, d_total);
+            QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, x.s));
+            QE_HIP(hipGetLastError());
+            QE_HIP(hipStreamSynchronize(x.s));
+            const int64_t kept = (int64_t)ctx->h_ctrl[1];
+            if (last && ctx->opts.result_capacity_rows > 0 && kept > ctx->opts.result_capacity_rows)   // same contract as the fused path
+                fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(kept) + " rows but result_capacity_rows is " +
+                                             std::to_string(ctx->opts.result_capacity_rows));
+            if (kept == x.n) { acc.reset(); continue; }           // everything survived: the domain stays as it is
+            if (!last && kept * 2 > x.n) continue;                // not selective enough to pay for a compaction yet: keep the mask
+            Buf rel = x.alloc((size_t)std::max<int64_t>(kept, 1) * 4);
+            pn::expand_indices(x.s, (const uint64_t *)acc.get(), nullptr, x.n, (const uint32_t *)offsets.get(), (uint32_t *)rel.get(), nw);
+            x.narrow(rel, kept);
+            acc.reset();
+        }
+        m = x.n;
+        // 3. the projections' columns that the final domain has not seen yet: one gather launch
         std::vector<char> used(x.env.size(), 0);
         for (int32_t i = 0; i < nproj; i++) collect_columns(projs[i]->e, used);
-        std::vector<Vec> compact(x.env.size());
-        const int64_t full_n = x.n;
-        x.n = m;
-        pn::GatherArgs ga{};
-        ga.idx = (const uint32_t *)idx.get();
-        ga.m = m;
-        auto flush = [&]() {
-            if (ga.ncols > 0 && m > 0) pn::gather_multi(x.s, ga);
-            ga.ncols = 0;
-        };
-        for (size_t j = 0; j < x.env.size(); j++) {
-            compact[j].type = x.env[j].type;
-            compact[j].dict = x.env[j].dict;
-            if (!used[j]) continue;
-            const Vec &src = x.env[j];
-            if (src.type == QE_BOOLEAN) {
-                compact[j].data = x.alloc_words();
-                pn::gather_bits(x.s, (const uint64_t *)src.data.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].data.get(), m);
-            } else {
-                compact[j].data = x.alloc_col(src.type);
-                ga.src[ga.ncols] = src.data.get();
-                ga.dst[ga.ncols] = compact[j].data.get();
-                ga.width[ga.ncols] = (int)width_of(src.type);
-                if (++ga.ncols == 8) flush();
-            }
-            if (src.valid) {
-                compact[j].valid = x.alloc_words();
-                pn::gather_bits(x.s, (const uint64_t *)src.valid.get(), (const uint32_t *)idx.get(), (uint64_t *)compact[j].valid.get(), m);
-            }
-        }
-        flush();
-        (void)full_n;
-        x.env.swap(compact);
-    } else if (ctx->opts.profile) {
-        QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        x.prefetch(used);
     }
     // 4. projections over the (compacted) domain
     res->count = m;
