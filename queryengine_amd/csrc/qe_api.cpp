@@ -499,6 +499,7 @@ namespace {
 // a plan that kept at least this share of its rows last time runs the dense single-pass kernel next time (measured
 // crossover against the LDS-ring kernel on cfg 2, 1 B rows: 10 % 4.14 vs 4.23 ms, 25 % 5.7 vs 4.5 ms)
 constexpr double kDenseFromSelectivity = 0.12;
+constexpr int kScatterWgsPerCu = 2;   // workgroups per CU of the partitioned group-by's scatter pass
 
 FusedGeometry geometry_of(const qe_ctx *ctx) {
     FusedGeometry g;
@@ -1421,7 +1422,12 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                     a.cnt_src[i] = cg.cnt_src[i];
                     a.fn[i] = agg_fns[i];
                 }
-                QE_HIP(hipModuleLaunchKernel(f_scatter, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+                // The scatter keeps one partially written line open per (wave, partition).  With every CU full of waves those open
+                // lines exceed the L2s and each 16-byte record left for HBM on its own (WRITE_SIZE 2x the record bytes); a smaller
+                // grid keeps the open lines resident until they are complete.
+                static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
+                const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
+                QE_HIP(hipModuleLaunchKernel(f_scatter, sgrid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
                 a.rec = p.desc;
                 a.rec_words = rec_words;
                 a.start = d_start;
