@@ -1377,7 +1377,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         QE_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         const int64_t n = batch->nrows;
         const bool no_partition = (ctx->opts.tuning[5] & 256) != 0;   // debug bit 256: keep the global-atomic path (A/B measurements, tests)
-        if (n > 0 && cg.partitioned && !no_partition) {
+        if (n > 0 && n < (1ll << 32) && cg.partitioned && !no_partition) {   // record positions are 32-bit in the scatter pass
             // Domain too large for an LDS table: count -> scan -> scatter -> per-partition LDS aggregation
             // (two streaming passes over the input and one over the records instead of one global atomic per value).
             const int P = cg.nparts;
