@@ -1415,7 +1415,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             if (m_records > 0) {
                 p.l1 = d_start;
                 const int rec_words = 1 + cg.nvals;
-                p.desc = (unsigned long long *)talloc((size_t)m_records * 8 * rec_words);
+                p.desc = (unsigned long long *)talloc((size_t)(m_records + 1) * 8 * rec_words);   // + the spare record the scatter's idle lanes write
                 GbAggArgs a{};
                 for (int i = 0; i < nagg; i++) {
                     a.slot[i] = cg.val_slot[i];
@@ -1427,7 +1427,22 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 // grid keeps the open lines resident until they are complete.
                 static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
                 const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
+                hipDeviceptr_t dbg = nullptr;
+                size_t dbg_bytes = 0;
+                if (ctx->opts.tuning[5] & 64) {
+                    QE_HIP(hipModuleGetGlobal(&dbg, &dbg_bytes, plan->kernel.module, "qe_dbg"));
+                    QE_HIP(hipMemsetAsync(dbg, 0, dbg_bytes, ctx->stream));
+                }
                 QE_HIP(hipModuleLaunchKernel(f_scatter, sgrid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+                if (dbg) {   // diagnostic build: shader clocks per phase, summed over the waves
+                    unsigned long long h[8] = {};
+                    QE_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                    QE_HIP(hipStreamSynchronize(ctx->stream));
+                    const double waves_total = (double)sgrid * waves;
+                    std::fprintf(stderr, "qe_gb_scatter phases, clocks per wave (grid %d x %d waves): issue loads %.0f | flush (stores) %.0f | "
+                                 "LDS sort %.0f | wait loads + evaluate %.0f | chunk drain %.0f\n", sgrid, waves, h[0] / waves_total,
+                                 h[1] / waves_total, h[2] / waves_total, h[3] / waves_total, h[4] / waves_total);
+                }
                 a.rec = p.desc;
                 a.rec_words = rec_words;
                 a.start = d_start;
@@ -1437,7 +1452,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 a.part_groups = cg.part_groups;
                 a.words = W;
                 a.nagg = nagg;
-                a.slices = std::max(1, std::min(64, 1024 / P));
+                a.slices = std::max(1, std::min(64, 2048 / P));   // ~2048 workgroups: every CU holds its share however the LDS tables pack
                 launch_gb_aggregate(ctx->stream, a);
             }
             if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -290,12 +290,12 @@ __device__ __forceinline__ u64 gb_init_word(const GbAggArgs &a, int w) {
 }
 
 // grid = (slices, nparts): workgroup (s, p) aggregates slice s of partition p's records in an LDS table.
-__global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
+__global__ void __launch_bounds__(1024) gb_aggregate_kernel(const GbAggArgs a) {
     extern __shared__ u64 s_tab[];
     const int part = blockIdx.y;
     const int W = a.words;
     const int nent = a.part_groups * W;
-    for (int i = threadIdx.x; i < nent; i += 256) s_tab[i] = gb_init_word(a, i % W);
+    for (int i = threadIdx.x; i < nent; i += blockDim.x) s_tab[i] = gb_init_word(a, i % W);
     __syncthreads();
     const u64 lo = a.start[part], hi = a.start[part + 1];
     const u64 len = hi - lo;
@@ -303,28 +303,45 @@ __global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
     const u64 b = lo + per * blockIdx.x;
     const u64 e = b + per < hi ? b + per : hi;
     const int RW = a.rec_words;
-    for (u64 i = b + threadIdx.x; i < e; i += 256) {
-        const u64 *rec = a.rec + i * (u64)RW;
-        u64 h, v0 = 0;
-        if (RW == 2) { const u64x2 t = *(const u64x2 *)rec; h = t.x; v0 = t.y; }
-        else h = rec[0];
-        u64 *ent = s_tab + (i64)((h >> 8) & 0xffffull) * W;
-        if ((h >> 24) < *(volatile u64 *)ent) atomicMin(ent, h >> 24);
+    // four records per thread in flight (one 16-byte load each left the memory system at ~3.6 TB/s)
+    constexpr int UN = 4;
+    for (u64 i0 = b; i0 < e; i0 += (u64)blockDim.x * UN) {
+        u64 hh[UN], vv[UN];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k < a.nagg && ((h >> k) & 1ull)) {
-                if (a.cnt_src[k] == k) atomicAdd(ent + 1 + 2 * k, 1ull);
-                const double v = __builtin_bit_cast(double, RW == 2 ? v0 : rec[1 + a.slot[k]]);
-                const int fn = a.fn[k];
-                if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(ent + 2 + 2 * k), v);
-                else if (fn == QE_AGG_MIN) atomicMin((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, true));
-                else if (fn == QE_AGG_MAX) atomicMax((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, false));
+        for (int q = 0; q < UN; ++q) {
+            const u64 i = i0 + (u64)q * blockDim.x + threadIdx.x;
+            hh[q] = 0ull;
+            vv[q] = 0ull;
+            if (i < e) {
+                const u64 *rec = a.rec + i * (u64)RW;
+                if (RW == 2) { const u64x2 t = __builtin_nontemporal_load((const u64x2 *)rec); hh[q] = t.x; vv[q] = t.y; }
+                else hh[q] = rec[0];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const u64 i = i0 + (u64)q * blockDim.x + threadIdx.x;
+            if (i >= e) break;
+            const u64 *rec = a.rec + i * (u64)RW;
+            const u64 h = hh[q], v0 = vv[q];
+            u64 *ent = s_tab + (i64)((h >> 8) & 0xffffull) * W;
+            if ((h >> 24) < *(volatile u64 *)ent) atomicMin(ent, h >> 24);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < a.nagg && ((h >> k) & 1ull)) {
+                    if (a.cnt_src[k] == k) atomicAdd(ent + 1 + 2 * k, 1ull);
+                    const double v = __builtin_bit_cast(double, RW == 2 ? v0 : rec[1 + a.slot[k]]);
+                    const int fn = a.fn[k];
+                    if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(ent + 2 + 2 * k), v);
+                    else if (fn == QE_AGG_MIN) atomicMin((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, true));
+                    else if (fn == QE_AGG_MAX) atomicMax((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, false));
+                }
             }
         }
     }
     __syncthreads();
     // merge into the global table (several slices may share a partition)
-    for (int g = threadIdx.x; g < a.part_groups; g += 256) {
+    for (int g = threadIdx.x; g < a.part_groups; g += blockDim.x) {
         const i64 gg = (i64)part * a.part_groups + g;
         const u64 *ent = s_tab + (i64)g * W;
         if (gg >= a.ngroups || ent[0] == ~0ull) continue;
@@ -344,7 +361,9 @@ __global__ void __launch_bounds__(256) gb_aggregate_kernel(const GbAggArgs a) {
 void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a) {
     if (a.nparts <= 0) return;
     const size_t lds = (size_t)a.part_groups * a.words * 8;
-    hipLaunchKernelGGL(gb_aggregate_kernel, dim3((unsigned)a.slices, (unsigned)a.nparts), dim3(256), lds, s, a);
+    const unsigned threads = lds > 48 * 1024 ? 1024u : 256u;   // a table that leaves room for one workgroup per CU: make it a big one
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)gb_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gb_aggregate_kernel, dim3((unsigned)a.slices, (unsigned)a.nparts), dim3(threads), lds, s, a);
 }
 
 // ---- bitmap segments (result concatenation / gather) -----------------------------------------------------------------
