@@ -1382,9 +1382,10 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             // (two streaming passes over the input and one over the records instead of one global atomic per value).
             const int P = cg.nparts;
             const int waves = plan->geo.threads / 64;
-            const int64_t chunk_rows = plan->geo.chunk_rows();
+            // a chunk = subs_per_chunk workgroup tiles (one sub-tile per wave each): the unit both passes hand to a workgroup
+            const int64_t chunk_rows = plan->geo.chunk_rows() * waves;
             const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 8));
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (int64_t)device_cus(ctx->device) * 8));
             hipFunction_t f_count = nullptr, f_scatter = nullptr;
             QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_gb_count"));
             QE_HIP(hipModuleGetFunction(&f_scatter, plan->kernel.module, "qe_gb_scatter"));
@@ -1415,13 +1416,8 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             if (m_records > 0) {
                 p.l1 = d_start;
                 const int rec_words = 1 + cg.nvals;
-                p.desc = (unsigned long long *)talloc((size_t)(m_records + 1) * 8 * rec_words);   // + the spare record the scatter's idle lanes write
-                GbAggArgs a{};
-                for (int i = 0; i < nagg; i++) {
-                    a.slot[i] = cg.val_slot[i];
-                    a.cnt_src[i] = cg.cnt_src[i];
-                    a.fn[i] = agg_fns[i];
-                }
+                if (m_records >= (1ull << 32)) fail(QE_ERR_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 records");
+                p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);   // + the spare line the scatter's idle threads write
                 // The scatter keeps one partially written line open per (wave, partition).  With every CU full of waves those open
                 // lines exceed the L2s and each 16-byte record left for HBM on its own (WRITE_SIZE 2x the record bytes); a smaller
                 // grid keeps the open lines resident until they are complete.
@@ -1443,17 +1439,15 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                                  "LDS sort %.0f | wait loads + evaluate %.0f | chunk drain %.0f\n", sgrid, waves, h[0] / waves_total,
                                  h[1] / waves_total, h[2] / waves_total, h[3] / waves_total, h[4] / waves_total);
                 }
-                a.rec = p.desc;
-                a.rec_words = rec_words;
-                a.start = d_start;
-                a.table = d_tab;
-                a.ngroups = G;
-                a.nparts = P;
-                a.part_groups = cg.part_groups;
-                a.words = W;
-                a.nagg = nagg;
-                a.slices = std::max(1, std::min(64, 2048 / P));   // ~2048 workgroups: every CU holds its share however the LDS tables pack
-                launch_gb_aggregate(ctx->stream, a);
+                // pass 3 (generated per plan): ~512 workgroups, one LDS table each, merged into the global table
+                static const int agg_wgs = std::getenv("QE_GB_AGG_WGS") ? std::atoi(std::getenv("QE_GB_AGG_WGS")) : 512;
+                const int slices = std::max(1, std::min(64, agg_wgs / P));
+                const size_t lds = (size_t)cg.part_groups * W * 8;
+                const int agg_threads = lds > 48 * 1024 ? 1024 : 256;   // a table that leaves room for one workgroup per CU: make it a big one
+                hipFunction_t f_agg = nullptr;
+                QE_HIP(hipModuleGetFunction(&f_agg, plan->kernel.module, "qe_gb_aggregate"));
+                p.agg_partial = (double *)d_tab;
+                QE_HIP(hipModuleLaunchKernel(f_agg, slices, P, 1, agg_threads, 1, 1, 0, ctx->stream, args, nullptr));
             }
             if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
             QE_HIP(hipStreamSynchronize(ctx->stream));   // the temporaries go back to the pool when this scope ends

@@ -21,20 +21,7 @@ void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, un
 // ---- partitioned group-by (domains that do not fit LDS) ----
 // counts[chunk][part] (kept rows) -> in place: offset of (chunk, part) inside its partition; totals[part] = rows of the partition
 void launch_gb_scan(hipStream_t s, uint32_t *counts, int64_t nchunks, int nparts, unsigned long long *totals);
-// aggregate the records of every partition in an LDS table of part_groups entries of `words` u64 words and merge it into
-// the global table (entry of local group g of partition p = table + (p * part_groups + g) * words)
-struct GbAggArgs {
-    const unsigned long long *rec;       // records of rec_words u64: {row:40 | local group:16 | non-null bits:8}, values (f64 bits)
-    int rec_words;
-    int slot[8];                         // per aggregate: which value of the record it consumes
-    int cnt_src[8];                      // per aggregate: the aggregate whose count word it shares (itself if nullable)
-    const unsigned long long *start;     // first record of every partition (nparts + 1 entries)
-    unsigned long long *table;
-    long long ngroups;
-    int nparts, part_groups, words, nagg, slices;
-    int fn[8];
-};
-void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a);
+
 
 // hashed group-by: fill a table of nentries entries with the per-word pattern of an empty entry; copy the entries in use
 // (state word == 2) to a dense array, *counter = how many

@@ -272,100 +272,6 @@ void launch_gb_scan(hipStream_t s, uint32_t *counts, int64_t nchunks, int nparts
     hipLaunchKernelGGL(gb_scan_kernel, dim3((unsigned)nparts), dim3(256), 0, s, counts, (i64)nchunks, nparts, (u64 *)totals);
 }
 
-// order-preserving i64 image of a double (the same function as the JIT prelude's qe_ord_key)
-__device__ __forceinline__ i64 gb_ord_key(double d, bool for_min) {
-    i64 b = __builtin_bit_cast(i64, d);
-    if (d != d) b = for_min ? (i64)0xfff8000000000000ull : (i64)0x7ff8000000000000ull;
-    return b ^ ((b >> 63) & 0x7fffffffffffffffll);
-}
-
-__device__ __forceinline__ u64 gb_init_word(const GbAggArgs &a, int w) {
-    if (w == 0) return ~0ull;
-    if ((w & 1) == 0) {
-        const int fn = a.fn[(w - 2) >> 1];
-        if (fn == QE_AGG_MIN) return 0x7fffffffffffffffull;
-        if (fn == QE_AGG_MAX) return 0x8000000000000000ull;
-    }
-    return 0ull;
-}
-
-// grid = (slices, nparts): workgroup (s, p) aggregates slice s of partition p's records in an LDS table.
-__global__ void __launch_bounds__(1024) gb_aggregate_kernel(const GbAggArgs a) {
-    extern __shared__ u64 s_tab[];
-    const int part = blockIdx.y;
-    const int W = a.words;
-    const int nent = a.part_groups * W;
-    for (int i = threadIdx.x; i < nent; i += blockDim.x) s_tab[i] = gb_init_word(a, i % W);
-    __syncthreads();
-    const u64 lo = a.start[part], hi = a.start[part + 1];
-    const u64 len = hi - lo;
-    const u64 per = (len + a.slices - 1) / a.slices;
-    const u64 b = lo + per * blockIdx.x;
-    const u64 e = b + per < hi ? b + per : hi;
-    const int RW = a.rec_words;
-    // four records per thread in flight (one 16-byte load each left the memory system at ~3.6 TB/s)
-    constexpr int UN = 4;
-    for (u64 i0 = b; i0 < e; i0 += (u64)blockDim.x * UN) {
-        u64 hh[UN], vv[UN];
-#pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            const u64 i = i0 + (u64)q * blockDim.x + threadIdx.x;
-            hh[q] = 0ull;
-            vv[q] = 0ull;
-            if (i < e) {
-                const u64 *rec = a.rec + i * (u64)RW;
-                if (RW == 2) { const u64x2 t = __builtin_nontemporal_load((const u64x2 *)rec); hh[q] = t.x; vv[q] = t.y; }
-                else hh[q] = rec[0];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < UN; ++q) {
-            const u64 i = i0 + (u64)q * blockDim.x + threadIdx.x;
-            if (i >= e) break;
-            const u64 *rec = a.rec + i * (u64)RW;
-            const u64 h = hh[q], v0 = vv[q];
-            u64 *ent = s_tab + (i64)((h >> 8) & 0xffffull) * W;
-            if ((h >> 24) < *(volatile u64 *)ent) atomicMin(ent, h >> 24);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k < a.nagg && ((h >> k) & 1ull)) {
-                    if (a.cnt_src[k] == k) atomicAdd(ent + 1 + 2 * k, 1ull);
-                    const double v = __builtin_bit_cast(double, RW == 2 ? v0 : rec[1 + a.slot[k]]);
-                    const int fn = a.fn[k];
-                    if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(ent + 2 + 2 * k), v);
-                    else if (fn == QE_AGG_MIN) atomicMin((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, true));
-                    else if (fn == QE_AGG_MAX) atomicMax((i64 *)(ent + 2 + 2 * k), gb_ord_key(v, false));
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // merge into the global table (several slices may share a partition)
-    for (int g = threadIdx.x; g < a.part_groups; g += blockDim.x) {
-        const i64 gg = (i64)part * a.part_groups + g;
-        const u64 *ent = s_tab + (i64)g * W;
-        if (gg >= a.ngroups || ent[0] == ~0ull) continue;
-        u64 *d = a.table + gg * W;
-        atomicMin(d, ent[0]);
-        for (int k = 0; k < a.nagg; ++k) {
-            if (ent[1 + 2 * a.cnt_src[k]] == 0) continue;
-            if (a.cnt_src[k] == k) atomicAdd(d + 1 + 2 * k, ent[1 + 2 * k]);
-            const int fn = a.fn[k];
-            if (fn == QE_AGG_SUM || fn == QE_AGG_AVG) atomicAdd((double *)(d + 2 + 2 * k), __builtin_bit_cast(double, ent[2 + 2 * k]));
-            else if (fn == QE_AGG_MIN) atomicMin((i64 *)(d + 2 + 2 * k), (i64)ent[2 + 2 * k]);
-            else if (fn == QE_AGG_MAX) atomicMax((i64 *)(d + 2 + 2 * k), (i64)ent[2 + 2 * k]);
-        }
-    }
-}
-
-void launch_gb_aggregate(hipStream_t s, const GbAggArgs &a) {
-    if (a.nparts <= 0) return;
-    const size_t lds = (size_t)a.part_groups * a.words * 8;
-    const unsigned threads = lds > 48 * 1024 ? 1024u : 256u;   // a table that leaves room for one workgroup per CU: make it a big one
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)gb_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gb_aggregate_kernel, dim3((unsigned)a.slices, (unsigned)a.nparts), dim3(threads), lds, s, a);
-}
-
 // ---- bitmap segments (result concatenation / gather) -----------------------------------------------------------------
 // Place `nbits` bits of `src` (bit i = word i>>6, bit i&63) at bit offset `dst_off` of `dst`.  One thread owns one
 // destination word, so the read-modify-write of the two boundary words is race free inside a launch; segments are placed
