@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(256) k_cmp(Ld<T> a, Ld<T> b, u64 *out, i64 n) 
 }
 
 template <typename T, int IEEE, int K> static void cmp_tk(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
-    const int g = grid_for((n + 511) / 512, 4, 256 * 8);   // 4 waves per workgroup, K 512-row chunks per wave and step
+    static const int wgs_per_cu = getenv("QE_PN_CMP_WGS") ? atoi(getenv("QE_PN_CMP_WGS")) : 4;   // 16 waves per CU: 1.25 - 1.28 ms per 8 GB column; 32 waves 1.43 ms
+    const int g = grid_for((n + 511) / 512, 4, 256 * wgs_per_cu);   // 4 waves per workgroup, K 512-row chunks per wave and step
     Ld<T> la = mk<T>(a), lb = mk<T>(b);
     switch (cmp) {
     case C_LT: hipLaunchKernelGGL((k_cmp<T, C_LT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
@@ -292,7 +293,10 @@ template <typename T, int IEEE, int K> static void cmp_tk(hipStream_t s, int cmp
     }
 }
 template <typename T, int IEEE> static void cmp_t(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
-    cmp_tk<T, IEEE, 1>(s, cmp, a, b, out, n);   // K = 2 (8 loads per operand in flight) measured the same: 1.34 - 1.41 ms per 8 GB
+    static const int k = getenv("QE_PN_CMP_K") ? atoi(getenv("QE_PN_CMP_K")) : 1;
+    if (k == 2) cmp_tk<T, IEEE, 2>(s, cmp, a, b, out, n);
+    else if (k == 4) cmp_tk<T, IEEE, 4>(s, cmp, a, b, out, n);
+    else cmp_tk<T, IEEE, 1>(s, cmp, a, b, out, n);   // K = 2 (8 loads per operand in flight) measured the same: 1.34 - 1.41 ms per 8 GB
 }
 
 void compare(hipStream_t s, int type, int cmp, int ieee, Opnd a, Opnd b, uint64_t *out, int64_t n) {
@@ -518,6 +522,8 @@ void expand_indices(hipStream_t s, const uint64_t *v, const uint64_t *k, int64_t
 // Gather of up to 8 value columns at the kept row ids, one output row per lane and step, 4 rows in flight per lane: every
 // lane of every load carries a row (a masked one-row-per-lane compaction straight from the bitmap was measured 2.8x
 // slower at 5 % selectivity: the address unit spends its cycles per wave instruction, not per active lane).
+// Round 2, second try at 10 %: streaming the column and compacting through the keep bitmap (masked stores, or an LDS buffer per
+// 512-row chunk and one coalesced store) took 1.71 - 1.78 ms per 8 GB column against 1.35 ms for this gather.
 __global__ void __launch_bounds__(256) k_gather_multi(const GatherArgs a) {
     const i64 stride = (i64)gridDim.x * blockDim.x;
     i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
