@@ -118,6 +118,7 @@ def cpu_baseline(workload, budget_s=12.0):
                       f"{total:.1f} s on 1 host core"}
 
 
+GATHER_TIMEOUT_S = 120
 CFG5_ROWS_PER_GPU = 10_000_000_000 // 8      # BASELINE.json configs[4]
 
 
@@ -253,24 +254,6 @@ def main():
     dt_max = float(t.item())
     total_out = int(cnt.item())
 
-    # the materialising exchange (cfg 5: "with and without the RCCL gather"); never part of `value`
-    gather_info = None
-    if (args.gather or world > 1) and not args.no_gather and not args.profile_run and not rehearsal:
-        try:
-            from queryengine_amd import distributed as QD
-            if world > 1:
-                QD.comm_init(ctx)
-            else:
-                ctx.comm_init(1, 0, ctx.comm_unique_id())
-            gather_info = QD.time_gather(ctx, batch, cf, cp, world, rank)
-            if world > 1:
-                tg = torch.tensor([gather_info["ms"], gather_info["scan_plus_gather_ms"]], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-                gather_info["ms"], gather_info["scan_plus_gather_ms"] = float(tg[0].item()), float(tg[1].item())
-            gather_info["rows_per_s_with_gather"] = world * nrows / (gather_info["scan_plus_gather_ms"] * 1e-3)
-        except Exception as exc:      # the exchange is a report beside the bench line, never a reason to lose it
-            gather_info = {"error": f"{type(exc).__name__}: {exc}"}
-
     # end to end including the result's way back to the host (SURVEY 8d "Timing"): step + D2H of every output column
     e2e_ms = None
     if not args.profile_run:
@@ -342,11 +325,53 @@ def main():
                                  "the fraction of peak the kernel really sustains", "algorithmic_bytes_per_launch": alg_bytes,
                          "measured_stream_read_gbps": stream_gbps},
         }
-        if gather_info is not None:
-            out["gather"] = gather_info
         if not args.no_cpu_baseline and world == 1 and not args.profile_run:
             out["cpu_baseline"] = cpu_baseline(wl)
+    else:
+        out = None
+
+    # The exchange runs LAST and under a watchdog: it is the one part of this file that no multi-GPU box has executed before
+    # the driver's own run, and a collective that never returns must not cost the bench line.  On expiry rank 0 prints the
+    # line (with the timeout recorded) and every rank leaves without tearing down the stuck communicator.
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out["gather"] = {"error": f"timeout: the exchange did not finish within {GATHER_TIMEOUT_S} s"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(GATHER_TIMEOUT_S, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    # the materialising exchange (cfg 5: "with and without the RCCL gather"); never part of `value`
+    gather_info = None
+    if (args.gather or world > 1) and not args.no_gather and not args.profile_run and not rehearsal:
+        try:
+            from queryengine_amd import distributed as QD
+            if world > 1:
+                QD.comm_init(ctx)
+            else:
+                ctx.comm_init(1, 0, ctx.comm_unique_id())
+            gather_info = QD.time_gather(ctx, batch, cf, cp, world, rank)
+            if world > 1:
+                tg = torch.tensor([gather_info["ms"], gather_info["scan_plus_gather_ms"]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                gather_info["ms"], gather_info["scan_plus_gather_ms"] = float(tg[0].item()), float(tg[1].item())
+            gather_info["rows_per_s_with_gather"] = world * nrows / (gather_info["scan_plus_gather_ms"] * 1e-3)
+        except Exception as exc:      # the exchange is a report beside the bench line, never a reason to lose it
+            gather_info = {"error": f"{type(exc).__name__}: {exc}"}
+
+    watchdog.cancel()
+    if rank == 0:
+        if gather_info is not None:
+            out["gather"] = gather_info
         print(json.dumps(out), flush=True)
+    if world > 1:   # the line is out: a teardown that hangs after a failed exchange must not hold the job
+        sys.stdout.flush()
+        late = threading.Timer(60, lambda: os._exit(0))
+        late.daemon = True
+        late.start()
     batch.free()
     ctx.close()
     if world > 1:
