@@ -499,6 +499,7 @@ namespace {
 // a plan that kept at least this share of its rows last time runs the dense single-pass kernel next time (measured
 // crossover against the LDS-ring kernel on cfg 2, 1 B rows: 10 % 4.14 vs 4.23 ms, 25 % 5.7 vs 4.5 ms)
 constexpr double kDenseFromSelectivity = 0.12;
+constexpr int64_t kSampleFromRows = 8ll << 20;   // batches from here on sample their selectivity before the first execution of a plan
 constexpr int kScatterWgsPerCu = 2;   // workgroups per CU of the partitioned group-by's scatter pass
 
 FusedGeometry geometry_of(const qe_ctx *ctx) {
@@ -827,6 +828,34 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     // Chosen from the selectivity the plan showed last time; supersedes the two-pass form (kept behind debug bit 512).
     const bool force_dense = (ctx->opts.tuning[5] & 16384) != 0, never_dense = (ctx->opts.tuning[5] & 32768) != 0;
     const double dense_from = std::getenv("QE_DENSE_FROM") ? std::atof(std::getenv("QE_DENSE_FROM")) : kDenseFromSelectivity;
+    // The FIRST execution of a plan knows nothing about its selectivity (a ring kernel that keeps every row costs 12 ms per
+    // 1 B rows where the dense form needs 6.3): estimate it from 256 chunks spread evenly over the batch -- the count pass
+    // of the two-pass form over ~4 M rows, filter columns only, a few tens of microseconds.
+    if (plan->cg.has_filter && plan->cg.two_pass && base->last_selectivity < 0 && !force_dense && !never_dense && !force_two_pass &&
+        n >= kSampleFromRows && (ctx->opts.tuning[5] & 65536) == 0) {
+        const int64_t chunk_rows = plan->geo.chunk_rows();
+        const int64_t full_chunks = n / chunk_rows;
+        const int64_t S = std::min<int64_t>(256, full_chunks);
+        if (S > 0) {
+            const int waves = plan->geo.threads / 64;
+            hipFunction_t f_count = nullptr;
+            QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_fp_count"));
+            uint32_t *d_sample = (uint32_t *)ctx->pool.alloc((size_t)S * 4);
+            struct SG { qe_ctx *c; void *q; ~SG() { c->pool.release(q); } } sg{ctx, d_sample};
+            FusedParams ps = p;
+            ps.nchunks = S;
+            ps.stagger_chunks = full_chunks / S;
+            ps.blk = (unsigned long long *)d_sample;
+            void *sargs[] = {&ps};
+            QE_HIP(hipModuleLaunchKernel(f_count, (unsigned)((S + waves - 1) / waves), 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, sargs, nullptr));
+            std::vector<uint32_t> h((size_t)S);
+            QE_HIP(hipMemcpyAsync(h.data(), d_sample, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            unsigned long long kept = 0;
+            for (uint32_t v : h) kept += v;
+            base->last_selectivity = (double)kept / (double)(S * chunk_rows);
+        }
+    }
     const bool dense = plan->cg.has_filter && !never_dense && !force_two_pass && (force_dense || base->last_selectivity >= dense_from);
     const bool two_pass = !dense && plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
                           (force_two_pass || base->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6

@@ -394,6 +394,40 @@ def test_dense_form_is_chosen_after_a_high_selectivity_run(oracle):
     ctx.close()
 
 
+def test_first_execution_samples_its_selectivity_on_a_large_batch(oracle):
+    """From 8 Mi rows on, the FIRST execution of a plan estimates its selectivity from 256 chunks spread over the batch (the
+    count pass of the two-pass form with a chunk stride) and starts in the form that fits: dense when the plan keeps >= 12 %
+    of its rows, the LDS ring otherwise.  Same rows either way: two windows are walked by the oracle, the count must equal
+    the next execution's, and debug bit 65536 switches the sample off (first execution = ring)."""
+    from queryengine_amd import engine as E
+    from queryengine_amd import workloads as W
+    n = 12_000_017
+    for a_limit, c_limit, want_form, tuning in ((1000, 1.0, N.FORM_DENSE, []), (400, 0.5, N.FORM_DENSE, []), (100, 0.5, N.FORM_RING, []),
+                                                (1000, 1.0, N.FORM_RING, [0, 0, 0, 0, 0, 65536])):
+        ctx = E.Context(device=0, tuning=tuning)
+        wl = W.config2(n, a_limit=a_limit, c_limit=c_limit)
+        batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
+        cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
+        res = E.filter_project(ctx, batch, cf, cp)
+        assert ctx.last_form == want_form, (a_limit, c_limit, ctx.last_form)
+        first = res.to_columns()
+        res.free()
+        res = E.filter_project(ctx, batch, cf, cp)
+        second = res.to_columns()
+        res.free()
+        for g, w in zip(first, second):
+            assert_columns_equal(g, w, f"a<{a_limit} c<{c_limit}: first vs second execution")
+        # the head of the batch, row by row, against the oracle
+        m = 70_000
+        host = [batch.column_to_host(j, 0, m) for j in range(batch.ncols)]
+        want = oracle.filter_project(host, wl.filter, wl.projections, oracle.BYTECODE_COMPILER)
+        k = len(want[0])
+        for g, w in zip(first, want):
+            assert_columns_equal(Column(g.type, g.data[:k], None, g.dictionary), w, f"a<{a_limit} c<{c_limit}: head window")
+        batch.free()
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", range(8 + int(os.environ.get("QE_FUZZ_EXTRA", "0"))))
 def test_random_conjunctive_filters(any_ctx, oracle, seed):
     """Filters that ARE top-level AND chains of 2-4 random boolean trees over null-heavy columns, several chunks of rows:
