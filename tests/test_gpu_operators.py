@@ -221,6 +221,35 @@ def test_group_by_large_domain_matches_oracle(case, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 1025, 4096, 4097, 65535, 65536, 65537, 131072 + 5, 200_000])
+def test_group_by_partitioned_sizes_around_tiles_and_chunks(n, oracle):
+    """The partitioned path works on workgroup tiles of 4096 rows (one 1024-row sub-tile per wave) and chunks of 16 tiles,
+    and pads every tile's records of a partition to whole 128-byte lines: batches smaller than a tile (idle waves), exactly
+    one tile / one chunk, one row more, and ragged tails must all give the reference's groups in insertion order."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(n)
+    nkeys = 5000
+    ctx = E.Context(device=0)
+    d = ["k%05d" % i for i in range(nkeys)]
+    s = Column(S, rng.integers(0, nkeys, n).astype(np.int32), None, d)
+    x = Column(D, np.round(rng.normal(0, 100, n)), rng.random(n) > 0.1)
+    y = Column(D, np.round(rng.normal(0, 10, n)))
+    Sx, X, Y = ColumnExpression("s", 0, S), ColumnExpression("x", 1, D), ColumnExpression("y", 2, D)
+    flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(5.0)], B)
+    batch = E.DeviceBatch.from_columns(ctx, [s, x, y])
+    for f, exprs, aggs in ((None, [Y, Y], [oracle.SUM, oracle.COUNT]), (flt, [X, Y, X], [oracle.SUM, oracle.MAX, oracle.COUNT]),
+                           (FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(-1000.0)], B), [Y], [oracle.MIN])):
+        res = E.filter_groupby(ctx, batch, ctx.compile(f) if f is not None else None, [ctx.compile(Sx)], [ctx.compile(e) for e in exprs], aggs)
+        cols = res.to_columns()
+        got = [[c.value(i) for c in cols] for i in range(res.count)]
+        res.free()
+        want = oracle.filter_groupby([s, x, y], f, [Sx], exprs, aggs, oracle.BYTECODE_COMPILER)
+        assert got == want, (n, aggs)
+    batch.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("path", ["lds", "partitioned", "global_atomics"])
 def test_group_by_counter_sharing_with_mixed_nullability(path, oracle):
     """Aggregates over non-nullable inputs share ONE row counter per group, nullable ones keep their own: every order
