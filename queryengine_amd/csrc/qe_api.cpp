@@ -610,6 +610,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
             plan->cg = generate_fused_source(in);
         }
     }
+    if (!in.group_keys.empty() && !plan->cg.hashed && !plan->cg.table_in_lds && ctx->opts.tuning[0] == 0 &&
+        (size_t)plan->cg.ngroups * plan->cg.table_words * 8 <= 144 * 1024) {
+        in.geo.threads = 1024;   // the table fits ONE workgroup's LDS: 16 waves per CU share it (see table_in_lds)
+        plan->cg = generate_fused_source(in);
+    }
     if (plan->cg.hashed && ctx->opts.tuning[1] == 0 && in.geo.unroll > 4) {
         in.geo.unroll = 4;   // hashed group-by: the key words of 2 * U rows live in registers next to the inputs; it is bound by atomics, not by loads in flight
         plan->cg = generate_fused_source(in);
@@ -1092,12 +1097,190 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     return res.release();
 }
 
+qe_result *run_groupby_dense(qe_ctx *ctx, const qe_batch *batch, const std::shared_ptr<Plan> &plan, const int32_t *agg_fns, int32_t nagg);
+
 // GroupByAggregation over arbitrary key tuples (a DOUBLE / INT64 / INT32 key, or more key combinations than a dense table
 // holds): the hashed form.  Global open-addressing table, grown (x8) and the kernel run again when it got more than half
 // full; the used entries are collected on the device, sorted by smallest row id on the host (LinkedHashMap insertion order,
 // GroupByAggregationOperator.kt:22) and finished like the dense form's (Accumulators.kt:26-107).
-qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const int32_t *agg_fns, int32_t nagg) {
+// Key columns of a hashed group-by result: row j's {null bits, key words..} come from `key_of(j)`.
+template <typename KeyOf>
+void append_key_columns(qe_ctx *ctx, const CodegenOutput &cg, qe_result *res, int64_t m, KeyOf key_of,
+                        std::vector<std::vector<unsigned long long>> &keep64, std::vector<std::vector<int32_t>> &keep32) {
+    const int NK = (int)cg.keys.size();
+    const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
+    auto upload = [&](const void *src, size_t bytes) -> void * {
+        void *d = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        if (bytes) QE_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return d;
+    };
+    for (int k = 0; k < NK; k++) {
+        OutColumn oc;
+        oc.type = cg.keys[k].type;
+        oc.dict = cg.keys[k].dict;
+        oc.dict_handle.d = oc.dict;
+        std::vector<unsigned long long> valid(words, 0), vals64((size_t)std::max<int64_t>(m, 1), 0), bits(words, 0);
+        std::vector<int32_t> vals32((size_t)std::max<int64_t>(m, 1), 0);
+        bool any_null = false;
+        for (int64_t j = 0; j < m; j++) {
+            const unsigned long long *e = key_of(j);   // {null bits, key words..}
+            if ((e[0] >> k) & 1ull) { any_null = true; continue; }
+            valid[j >> 6] |= 1ull << (j & 63);
+            const unsigned long long kw = e[1 + k];
+            vals64[j] = kw;                       // DOUBLE: the canonical bits ARE the value; INT64: the value
+            vals32[j] = (int32_t)(int64_t)kw;     // INT32 / dictionary codes
+            if (kw) bits[j >> 6] |= 1ull << (j & 63);
+        }
+        oc.nullable = any_null;
+        if (oc.type == QE_BOOLEAN) {
+            keep64.push_back(bits);
+            oc.data = upload(keep64.back().data(), words * 8);
+        } else if (oc.type == QE_DOUBLE || oc.type == QE_INT64) {
+            keep64.push_back(vals64);
+            oc.data = upload(keep64.back().data(), (size_t)m * 8);
+        } else {
+            keep32.push_back(vals32);
+            oc.data = upload(keep32.back().data(), (size_t)m * 4);
+        }
+        if (any_null) {
+            keep64.push_back(valid);
+            oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
+        }
+        res->cols.push_back(oc);
+    }
+}
+
+// Hashed group-by whose keys do not fit the LDS table: (1) qe_ht_build gives every key a dense id (global open-addressing
+// table, a 64 KiB id cache per workgroup; after its first rows a key is only READ) and writes the id of every kept row;
+// (2) the dense group-by -- LDS-privatised table or the partitioned passes -- runs on the id column; (3) the ids of the result
+// rows are turned back into key values.  nullptr: more keys than a dense table takes (the caller keeps the global-atomic form).
+qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const qe_expr *filter, const qe_expr *const *exprs,
+                           const int32_t *agg_fns, int32_t nagg) {
     const CodegenOutput &cg = plan.cg;
+    const int NK = (int)cg.keys.size(), BW = 3 + NK;
+    const int64_t n = batch->nrows;
+    std::vector<void *> temps;
+    struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
+    auto talloc = [&](size_t bytes) { void *q = ctx->pool.alloc(std::max<size_t>(bytes, 16)); temps.push_back(q); return q; };
+    uint32_t *d_ids = (uint32_t *)talloc((size_t)n * 4);
+    hipFunction_t f_build = nullptr;
+    QE_HIP(hipModuleGetFunction(&f_build, plan.kernel.module, "qe_ht_build"));
+    int64_t C = plan.id_capacity > 0 ? plan.id_capacity : (1ll << 16);
+    int64_t D = 0;
+    unsigned long long *d_keys = nullptr;
+    double build_ms = 0.0;
+    for (;;) {
+        unsigned long long *d_tab = (unsigned long long *)talloc((size_t)C * BW * 8);
+        d_keys = (unsigned long long *)talloc((size_t)C * (1 + NK) * 8);
+        QE_HIP(hipMemsetAsync(d_tab, 0, (size_t)C * BW * 8, ctx->stream));
+        QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+        const int64_t sub_rows = plan.geo.sub_rows();
+        const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
+        const int waves = plan.geo.threads / 64;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 4));
+        FusedParams p;
+        fill_inputs(p, batch, plan);
+        p.agg_partial = (double *)d_tab;
+        p.capacity = C;
+        p.ticket = ctx->d_ctrl;
+        p.error = ctx->d_ctrl + 1;
+        p.desc = d_keys;
+        p.blk = (unsigned long long *)d_ids;
+        void *args[] = {&p};
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        QE_HIP(hipModuleLaunchKernel(f_build, grid, 1, 1, plan.geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 32, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->opts.profile) {
+            float ms = 0.f;
+            QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            build_ms += ms;
+        }
+        const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+        if (hc[1] != 0) {   // more than half full: a bigger table, again (the launch stopped at once: an attempt costs little)
+            if (C >= (1ll << 22)) return nullptr;
+            C *= 4;
+            continue;
+        }
+        D = hc[0];
+        break;
+    }
+    plan.id_capacity = C;
+    if (D > (1ll << 20) - 1) return nullptr;   // a dense table takes 2^20 groups (the id domain + its NULL code)
+    // (2) the dense group-by over [the batch's columns.., ids]: the id column is a dictionary-coded key whose dictionary is a
+    // placeholder of 2^k entries (only its size matters: the domain of the group id)
+    int64_t dom = 2;
+    while (dom < D) dom *= 2;
+    dom = std::min<int64_t>(dom, (1ll << 20) - 1);
+    std::shared_ptr<DictData> &idd = ctx->id_dicts[dom];
+    if (!idd) {
+        idd = std::make_shared<DictData>();
+        idd->entries.resize((size_t)dom);
+    }
+    qe_batch tmp;
+    tmp.nrows = n;
+    tmp.cols = batch->cols;
+    for (Column &c : tmp.cols) c.owned = false;
+    Column idc;
+    idc.type = QE_STRING;
+    idc.data = d_ids;
+    idc.validity = nullptr;
+    idc.dict = idd;
+    idc.owned = false;
+    tmp.cols.push_back(idc);
+    qe_expr kx;
+    {
+        Node nd;
+        nd.kind = N_COLUMN;
+        nd.type = QE_STRING;
+        nd.col = (int)batch->cols.size();
+        kx.e.nodes.push_back(nd);
+        kx.e.root = 0;
+        kx.e.max_stack = 1;
+        const char tag[] = "\xEEid-column";
+        kx.e.program.assign(tag, tag + sizeof tag - 1);
+        kx.e.program.push_back((uint8_t)batch->cols.size());
+    }
+    const qe_expr *kp[1] = {&kx};
+    auto dplan = get_plan(ctx, &tmp, filter, exprs, nagg, agg_fns, true, kp, 1);
+    if (dplan->cg.hashed) fail(QE_ERR_INTERNAL, "dense-id plan came out hashed");
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> r(run_groupby_dense(ctx, &tmp, dplan, agg_fns, nagg),
+                                                                   [ctx](qe_result *q) { free_result(ctx, q); });
+    if (ctx->opts.profile) {   // one step = build pass + dense passes
+        ctx->last_ms += build_ms;
+        ctx->total_ms += build_ms;
+    }
+    // (3) ids of the result rows (column 0, in insertion order) -> key values
+    const int64_t m = r->count;
+    std::vector<int32_t> rid((size_t)std::max<int64_t>(m, 1));
+    std::vector<unsigned long long> hkeys((size_t)std::max<int64_t>(D, 1) * (1 + NK));
+    if (m > 0) QE_HIP(hipMemcpyAsync(rid.data(), r->cols[0].data, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (D > 0) QE_HIP(hipMemcpyAsync(hkeys.data(), d_keys, (size_t)D * (1 + NK) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *q) { free_result(ctx, q); });
+    res->count = m;
+    res->capacity = m;
+    std::vector<std::vector<unsigned long long>> keep64;
+    std::vector<std::vector<int32_t>> keep32;
+    append_key_columns(ctx, cg, res.get(), m, [&](int64_t j) { return &hkeys[(size_t)rid[(size_t)j] * (1 + NK)]; }, keep64, keep32);
+    for (size_t c = 1; c < r->cols.size(); c++) {   // the aggregates move over as they are
+        res->cols.push_back(r->cols[c]);
+        r->cols[c].data = nullptr;
+        r->cols[c].validity = nullptr;
+    }
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    return res.release();
+}
+
+qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const qe_expr *filter, const qe_expr *const *exprs,
+                              const int32_t *agg_fns, int32_t nagg) {
+    const CodegenOutput &cg = plan.cg;
+    const bool ids_allowed = (ctx->opts.tuning[5] & 131072) == 0 && batch->nrows < (1ll << 32);   // debug bit 131072: keep the global-atomic form
+    if (plan.use_ids && ids_allowed) {
+        qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
+        if (r) return r;
+    }
     const int W = cg.hash_words, NK = (int)cg.keys.size(), ACC = 2 + NK;
     if (W > 40) fail(QE_ERR_UNSUPPORTED, "too many GROUP BY keys + aggregates for one hash entry");
     const int64_t n = batch->nrows;
@@ -1109,6 +1292,7 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
         init.word[ACC + 2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
     std::vector<unsigned long long> dense;
     int64_t m = 0;
+    bool ids_failed = false;
     if (n > 0) {
         int64_t C = plan.hash_capacity > 0 ? plan.hash_capacity : (1ll << 16);
         for (;;) {
@@ -1126,11 +1310,19 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             p.capacity = C;
             p.ticket = ctx->d_ctrl;
             p.error = ctx->d_ctrl + 1;
+            p.stagger_chunks = ids_allowed && !ids_failed ? 1 : 0;   // a key that finds no room in LDS stops the launch (error 4) instead of going global
             launch_fused(ctx, plan, p, grid);
             QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 16, hipMemcpyDeviceToHost, ctx->stream));
             QE_HIP(hipStreamSynchronize(ctx->stream));
-            collect_time(ctx);
             const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+            if (hc[1] == 4) {   // the keys do not fit the LDS table: dense ids from now on (this execution included)
+                plan.use_ids = true;
+                qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
+                if (r) return r;
+                ids_failed = true;   // more keys than a dense table takes: the global-atomic form after all
+                continue;
+            }
+            collect_time(ctx);
             if (hc[1] != 0) {   // more than half full (or a probe sequence ran out): a bigger table, again
                 if (C >= (1ll << 28)) fail(QE_ERR_UNSUPPORTED, "GROUP BY produced more than 2^27 groups");
                 C *= 8;
@@ -1138,6 +1330,10 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             }
             plan.hash_capacity = C;
             const int64_t used = hc[0];
+            // more than a few dozen keys: probing the LDS table costs more than resolving ids first (300 keys: 15 ms here,
+            // ~6 ms as build pass + dense LDS group-by) -- the next executions of this plan go that way
+            static const int64_t ids_from = std::getenv("QE_IDS_FROM") ? std::atoll(std::getenv("QE_IDS_FROM")) : 128;
+            if (used > ids_from && ids_allowed) plan.use_ids = true;
             unsigned long long *d_dense = (unsigned long long *)ctx->pool.alloc((size_t)std::max<int64_t>(used, 1) * W * 8);
             struct G2 { qe_ctx *c; void *p; ~G2() { c->pool.release(p); } } g2{ctx, d_dense};
             QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));
@@ -1165,40 +1361,7 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
     };
     std::vector<std::vector<unsigned long long>> keep64;   // host staging must outlive the async copies
     std::vector<std::vector<int32_t>> keep32;
-    for (int k = 0; k < NK; k++) {
-        OutColumn oc;
-        oc.type = cg.keys[k].type;
-        oc.dict = cg.keys[k].dict;
-        oc.dict_handle.d = oc.dict;
-        std::vector<unsigned long long> valid(words, 0), vals64((size_t)std::max<int64_t>(m, 1), 0), bits(words, 0);
-        std::vector<int32_t> vals32((size_t)std::max<int64_t>(m, 1), 0);
-        bool any_null = false;
-        for (int64_t j = 0; j < m; j++) {
-            const unsigned long long *e = &dense[(size_t)order[j].second * W];
-            if ((e[1] >> k) & 1ull) { any_null = true; continue; }
-            valid[j >> 6] |= 1ull << (j & 63);
-            const unsigned long long kw = e[2 + k];
-            vals64[j] = kw;                       // DOUBLE: the canonical bits ARE the value; INT64: the value
-            vals32[j] = (int32_t)(int64_t)kw;     // INT32 / dictionary codes
-            if (kw) bits[j >> 6] |= 1ull << (j & 63);
-        }
-        oc.nullable = any_null;
-        if (oc.type == QE_BOOLEAN) {
-            keep64.push_back(bits);
-            oc.data = upload(keep64.back().data(), words * 8);
-        } else if (oc.type == QE_DOUBLE || oc.type == QE_INT64) {
-            keep64.push_back(vals64);
-            oc.data = upload(keep64.back().data(), (size_t)m * 8);
-        } else {
-            keep32.push_back(vals32);
-            oc.data = upload(keep32.back().data(), (size_t)m * 4);
-        }
-        if (any_null) {
-            keep64.push_back(valid);
-            oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
-        }
-        res->cols.push_back(oc);
-    }
+    append_key_columns(ctx, cg, res.get(), m, [&](int64_t j) { return &dense[(size_t)order[(size_t)j].second * W + 1]; }, keep64, keep32);
     std::vector<std::vector<double>> keep_vals;
     for (int i = 0; i < nagg; i++) {
         OutColumn oc;
@@ -1233,6 +1396,230 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
         if (any_null) {
             keep64.push_back(valid);
             oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
+        }
+        res->cols.push_back(oc);
+    }
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    return res.release();
+}
+
+// GroupByAggregation over a dense group id (dictionary / boolean keys): LDS-privatised table, partitioned passes or global
+// atomics, the groups finished on the host in insertion order.
+qe_result *run_groupby_dense(qe_ctx *ctx, const qe_batch *batch, const std::shared_ptr<Plan> &plan, const int32_t *agg_fns, int32_t nagg) {
+    const CodegenOutput &cg = plan->cg;
+    const int64_t G = cg.ngroups;
+    const int W = cg.table_words;
+    // global accumulator table, initialised from the host (smallest row = ~0, MIN/MAX keys at their identity)
+    const int copies = cg.table_copies;
+    std::vector<unsigned long long> tab((size_t)G * W * copies);
+    for (int64_t g = 0; g < G * copies; g++) {
+        unsigned long long *e = &tab[(size_t)g * W];
+        e[0] = ~0ull;
+        for (int i = 0; i < nagg; i++) {
+            e[1 + 2 * i] = 0;
+            e[2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
+        }
+    }
+    unsigned long long *d_tab = (unsigned long long *)ctx->pool.alloc(tab.size() * 8);
+    struct G1 { qe_ctx *c; void *p; ~G1() { c->pool.release(p); } } g1{ctx, d_tab};
+    QE_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t n = batch->nrows;
+    const bool no_partition = (ctx->opts.tuning[5] & 256) != 0;   // debug bit 256: keep the global-atomic path (A/B measurements, tests)
+    if (n > 0 && n < (1ll << 32) && cg.partitioned && !no_partition) {   // record positions are 32-bit in the scatter pass
+        // Domain too large for an LDS table: count -> scan -> scatter -> per-partition LDS aggregation
+        // (two streaming passes over the input and one over the records instead of one global atomic per value).
+        const int P = cg.nparts;
+        const int waves = plan->geo.threads / 64;
+        // a chunk = subs_per_chunk workgroup tiles (one sub-tile per wave each): the unit both passes hand to a workgroup
+        const int64_t chunk_rows = plan->geo.chunk_rows() * waves;
+        const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (int64_t)device_cus(ctx->device) * 8));
+        hipFunction_t f_count = nullptr, f_scatter = nullptr;
+        QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_gb_count"));
+        QE_HIP(hipModuleGetFunction(&f_scatter, plan->kernel.module, "qe_gb_scatter"));
+        std::vector<void *> temps;
+        struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
+        auto talloc = [&](size_t bytes) { void *q = ctx->pool.alloc(std::max<size_t>(bytes, 16)); temps.push_back(q); return q; };
+        uint32_t *d_counts = (uint32_t *)talloc((size_t)nchunks * P * 4);
+        unsigned long long *d_start = (unsigned long long *)talloc((size_t)(P + 1) * 8);
+        FusedParams p;
+        fill_inputs(p, batch, *plan);
+        p.nchunks = nchunks;
+        p.blk = (unsigned long long *)d_counts;
+        void *args[] = {&p};
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        QE_HIP(hipModuleLaunchKernel(f_count, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+        launch_gb_scan(ctx->stream, d_counts, nchunks, P, d_start);
+        std::vector<unsigned long long> start((size_t)P + 1, 0);
+        QE_HIP(hipMemcpyAsync(start.data(), d_start, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));
+        unsigned long long m_records = 0;
+        for (int j = 0; j < P; j++) {
+            const unsigned long long cnt = start[j];
+            start[j] = m_records;
+            m_records += cnt;
+        }
+        start[P] = m_records;
+        QE_HIP(hipMemcpyAsync(d_start, start.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (m_records > 0) {
+            p.l1 = d_start;
+            const int rec_words = 1 + cg.nvals;
+            if (m_records >= (1ull << 32)) fail(QE_ERR_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 records");
+            p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);   // + the spare line the scatter's idle threads write
+            // The scatter keeps one partially written line open per (wave, partition).  With every CU full of waves those open
+            // lines exceed the L2s and each 16-byte record left for HBM on its own (WRITE_SIZE 2x the record bytes); a smaller
+            // grid keeps the open lines resident until they are complete.
+            static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
+            const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
+            hipDeviceptr_t dbg = nullptr;
+            size_t dbg_bytes = 0;
+            if (ctx->opts.tuning[5] & 64) {
+                QE_HIP(hipModuleGetGlobal(&dbg, &dbg_bytes, plan->kernel.module, "qe_dbg"));
+                QE_HIP(hipMemsetAsync(dbg, 0, dbg_bytes, ctx->stream));
+            }
+            QE_HIP(hipModuleLaunchKernel(f_scatter, sgrid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+            if (dbg) {   // diagnostic build: shader clocks per phase, summed over the waves
+                unsigned long long h[8] = {};
+                QE_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                QE_HIP(hipStreamSynchronize(ctx->stream));
+                const double waves_total = (double)sgrid * waves;
+                std::fprintf(stderr, "qe_gb_scatter phases, clocks per wave (grid %d x %d waves): issue loads %.0f | flush (stores) %.0f | "
+                             "LDS sort %.0f | wait loads + evaluate %.0f | chunk drain %.0f\n", sgrid, waves, h[0] / waves_total,
+                             h[1] / waves_total, h[2] / waves_total, h[3] / waves_total, h[4] / waves_total);
+            }
+            // pass 3 (generated per plan): ~512 workgroups, one LDS table each, merged into the global table
+            static const int agg_wgs = std::getenv("QE_GB_AGG_WGS") ? std::atoi(std::getenv("QE_GB_AGG_WGS")) : 512;
+            const int slices = std::max(1, std::min(64, agg_wgs / P));
+            const size_t lds = (size_t)cg.part_groups * W * 8;
+            const int agg_threads = lds > 48 * 1024 ? 1024 : 256;   // a table that leaves room for one workgroup per CU: make it a big one
+            hipFunction_t f_agg = nullptr;
+            QE_HIP(hipModuleGetFunction(&f_agg, plan->kernel.module, "qe_gb_aggregate"));
+            p.agg_partial = (double *)d_tab;
+            QE_HIP(hipModuleLaunchKernel(f_agg, slices, P, 1, agg_threads, 1, 1, 0, ctx->stream, args, nullptr));
+        }
+        if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        QE_HIP(hipStreamSynchronize(ctx->stream));   // the temporaries go back to the pool when this scope ends
+    } else if (n > 0) {
+        const int64_t sub_rows = plan->geo.sub_rows();
+        const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
+        const int waves = plan->geo.threads / 64;
+        const int wgs_per_cu = plan->geo.threads >= 1024 ? 1 : 4;   // a 1024-thread workgroup owns its CU (and merges its table once)
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves, (int64_t)device_cus(ctx->device) * wgs_per_cu));
+        FusedParams p;
+        fill_inputs(p, batch, *plan);
+        p.agg_partial = (double *)d_tab;
+        launch_fused(ctx, *plan, p, grid);
+    }
+    QE_HIP(hipMemcpyAsync(tab.data(), d_tab, tab.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    if (n > 0) collect_time(ctx);
+    // fold the per-XCD copies into copy 0, in XCD order
+    for (int c = 1; c < copies; c++) {
+        for (int64_t g = 0; g < G; g++) {
+            unsigned long long *d = &tab[(size_t)g * W];
+            const unsigned long long *e = &tab[((size_t)c * G + g) * W];
+            if (e[0] == ~0ull) continue;
+            d[0] = std::min(d[0], e[0]);
+            for (int i = 0; i < nagg; i++) {
+                if (e[1 + 2 * cg.cnt_src[i]] == 0) continue;
+                if (cg.cnt_src[i] == i) d[1 + 2 * i] += e[1 + 2 * i];
+                if (agg_fns[i] == QE_AGG_SUM || agg_fns[i] == QE_AGG_AVG) {
+                    double a, b;
+                    std::memcpy(&a, &d[2 + 2 * i], 8);
+                    std::memcpy(&b, &e[2 + 2 * i], 8);
+                    a += b;
+                    std::memcpy(&d[2 + 2 * i], &a, 8);
+                } else if (agg_fns[i] == QE_AGG_MIN) {
+                    d[2 + 2 * i] = (unsigned long long)std::min((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
+                } else if (agg_fns[i] == QE_AGG_MAX) {
+                    d[2 + 2 * i] = (unsigned long long)std::max((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
+                }
+            }
+        }
+    }
+    // groups in insertion order = ascending first row (LinkedHashMap order, GroupByAggregationOperator.kt:22)
+    std::vector<std::pair<unsigned long long, int64_t>> order;
+    for (int64_t g = 0; g < G; g++)
+        if (tab[(size_t)g * W] != ~0ull) order.emplace_back(tab[(size_t)g * W], g);
+    std::sort(order.begin(), order.end());
+    const int64_t m = (int64_t)order.size();
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
+    res->count = m;
+    res->capacity = m;
+    const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
+    auto upload = [&](const void *src, size_t bytes) -> void * {
+        void *d = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        if (bytes) QE_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return d;
+    };
+    std::vector<std::vector<unsigned long long>> keep_words;   // host staging must outlive the async copies
+    std::vector<std::vector<int32_t>> keep_codes;
+    std::vector<std::vector<double>> keep_vals;
+    int64_t stride = 1;
+    for (size_t k = 0; k < cg.keys.size(); k++) {
+        const int domain = cg.key_domain[k];
+        OutColumn oc;
+        oc.type = cg.keys[k].type;
+        oc.dict = cg.keys[k].dict;
+        oc.dict_handle.d = oc.dict;
+        std::vector<unsigned long long> valid(words, 0), bits(words, 0);
+        std::vector<int32_t> codes((size_t)std::max<int64_t>(m, 1), 0);
+        bool any_null = false;
+        for (int64_t j = 0; j < m; j++) {
+            const int code = (int)((order[j].second / stride) % (domain + 1));
+            if (code == domain) { any_null = true; continue; }
+            valid[j >> 6] |= 1ull << (j & 63);
+            codes[j] = code;
+            if (code) bits[j >> 6] |= 1ull << (j & 63);
+        }
+        oc.nullable = any_null;
+        if (oc.type == QE_BOOLEAN) {
+            keep_words.push_back(bits);
+            oc.data = upload(keep_words.back().data(), words * 8);
+        } else {
+            keep_codes.push_back(codes);
+            oc.data = upload(keep_codes.back().data(), (size_t)m * 4);
+        }
+        if (any_null) {
+            keep_words.push_back(valid);
+            oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
+        }
+        res->cols.push_back(oc);
+        stride *= (domain + 1);
+    }
+    for (int i = 0; i < nagg; i++) {
+        OutColumn oc;
+        oc.type = QE_DOUBLE;
+        std::vector<double> vals((size_t)std::max<int64_t>(m, 1), 0.0);
+        std::vector<unsigned long long> valid(words, 0);
+        bool any_null = false;
+        for (int64_t j = 0; j < m; j++) {
+            const unsigned long long *e = &tab[(size_t)order[j].second * W];
+            const unsigned long long cnt = e[1 + 2 * cg.cnt_src[i]];
+            const unsigned long long raw = e[2 + 2 * i];
+            double v = 0.0;
+            bool ok = true;
+            switch (agg_fns[i]) {
+            case QE_AGG_COUNT: v = (double)cnt; break;                       // Accumulators.kt:26-36
+            case QE_AGG_SUM: std::memcpy(&v, &raw, 8); ok = cnt != 0; break;  // :47-53 empty => null
+            case QE_AGG_AVG: std::memcpy(&v, &raw, 8); ok = cnt != 0; if (ok) v /= (double)cnt; break;
+            default: {                                                        // MIN / MAX: undo the ordered key
+                long long key = (long long)raw;
+                long long b = key ^ ((key >> 63) & 0x7fffffffffffffffll);
+                std::memcpy(&v, &b, 8);
+                ok = cnt != 0;
+            }
+            }
+            if (ok) valid[j >> 6] |= 1ull << (j & 63);
+            else { any_null = true; v = 0.0; }
+            vals[j] = v;
+        }
+        oc.nullable = any_null;
+        keep_vals.push_back(vals);
+        oc.data = upload(keep_vals.back().data(), (size_t)m * 8);
+        if (any_null) {
+            keep_words.push_back(valid);
+            oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
         }
         res->cols.push_back(oc);
     }
@@ -1402,226 +1789,10 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         auto plan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true, keys, nkeys);
         const CodegenOutput &cg = plan->cg;
         if (cg.hashed) {
-            *out = run_groupby_hashed(ctx, batch, *plan, agg_fns, nagg);
+            *out = run_groupby_hashed(ctx, batch, *plan, filter, exprs, agg_fns, nagg);
             return;
         }
-        const int64_t G = cg.ngroups;
-        const int W = cg.table_words;
-        // global accumulator table, initialised from the host (smallest row = ~0, MIN/MAX keys at their identity)
-        const int copies = cg.table_copies;
-        std::vector<unsigned long long> tab((size_t)G * W * copies);
-        for (int64_t g = 0; g < G * copies; g++) {
-            unsigned long long *e = &tab[(size_t)g * W];
-            e[0] = ~0ull;
-            for (int i = 0; i < nagg; i++) {
-                e[1 + 2 * i] = 0;
-                e[2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
-            }
-        }
-        unsigned long long *d_tab = (unsigned long long *)ctx->pool.alloc(tab.size() * 8);
-        struct G1 { qe_ctx *c; void *p; ~G1() { c->pool.release(p); } } g1{ctx, d_tab};
-        QE_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        const int64_t n = batch->nrows;
-        const bool no_partition = (ctx->opts.tuning[5] & 256) != 0;   // debug bit 256: keep the global-atomic path (A/B measurements, tests)
-        if (n > 0 && n < (1ll << 32) && cg.partitioned && !no_partition) {   // record positions are 32-bit in the scatter pass
-            // Domain too large for an LDS table: count -> scan -> scatter -> per-partition LDS aggregation
-            // (two streaming passes over the input and one over the records instead of one global atomic per value).
-            const int P = cg.nparts;
-            const int waves = plan->geo.threads / 64;
-            // a chunk = subs_per_chunk workgroup tiles (one sub-tile per wave each): the unit both passes hand to a workgroup
-            const int64_t chunk_rows = plan->geo.chunk_rows() * waves;
-            const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, (int64_t)device_cus(ctx->device) * 8));
-            hipFunction_t f_count = nullptr, f_scatter = nullptr;
-            QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_gb_count"));
-            QE_HIP(hipModuleGetFunction(&f_scatter, plan->kernel.module, "qe_gb_scatter"));
-            std::vector<void *> temps;
-            struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
-            auto talloc = [&](size_t bytes) { void *q = ctx->pool.alloc(std::max<size_t>(bytes, 16)); temps.push_back(q); return q; };
-            uint32_t *d_counts = (uint32_t *)talloc((size_t)nchunks * P * 4);
-            unsigned long long *d_start = (unsigned long long *)talloc((size_t)(P + 1) * 8);
-            FusedParams p;
-            fill_inputs(p, batch, *plan);
-            p.nchunks = nchunks;
-            p.blk = (unsigned long long *)d_counts;
-            void *args[] = {&p};
-            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-            QE_HIP(hipModuleLaunchKernel(f_count, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
-            launch_gb_scan(ctx->stream, d_counts, nchunks, P, d_start);
-            std::vector<unsigned long long> start((size_t)P + 1, 0);
-            QE_HIP(hipMemcpyAsync(start.data(), d_start, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
-            QE_HIP(hipStreamSynchronize(ctx->stream));
-            unsigned long long m_records = 0;
-            for (int j = 0; j < P; j++) {
-                const unsigned long long cnt = start[j];
-                start[j] = m_records;
-                m_records += cnt;
-            }
-            start[P] = m_records;
-            QE_HIP(hipMemcpyAsync(d_start, start.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            if (m_records > 0) {
-                p.l1 = d_start;
-                const int rec_words = 1 + cg.nvals;
-                if (m_records >= (1ull << 32)) fail(QE_ERR_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 records");
-                p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);   // + the spare line the scatter's idle threads write
-                // The scatter keeps one partially written line open per (wave, partition).  With every CU full of waves those open
-                // lines exceed the L2s and each 16-byte record left for HBM on its own (WRITE_SIZE 2x the record bytes); a smaller
-                // grid keeps the open lines resident until they are complete.
-                static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
-                const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
-                hipDeviceptr_t dbg = nullptr;
-                size_t dbg_bytes = 0;
-                if (ctx->opts.tuning[5] & 64) {
-                    QE_HIP(hipModuleGetGlobal(&dbg, &dbg_bytes, plan->kernel.module, "qe_dbg"));
-                    QE_HIP(hipMemsetAsync(dbg, 0, dbg_bytes, ctx->stream));
-                }
-                QE_HIP(hipModuleLaunchKernel(f_scatter, sgrid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
-                if (dbg) {   // diagnostic build: shader clocks per phase, summed over the waves
-                    unsigned long long h[8] = {};
-                    QE_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-                    QE_HIP(hipStreamSynchronize(ctx->stream));
-                    const double waves_total = (double)sgrid * waves;
-                    std::fprintf(stderr, "qe_gb_scatter phases, clocks per wave (grid %d x %d waves): issue loads %.0f | flush (stores) %.0f | "
-                                 "LDS sort %.0f | wait loads + evaluate %.0f | chunk drain %.0f\n", sgrid, waves, h[0] / waves_total,
-                                 h[1] / waves_total, h[2] / waves_total, h[3] / waves_total, h[4] / waves_total);
-                }
-                // pass 3 (generated per plan): ~512 workgroups, one LDS table each, merged into the global table
-                static const int agg_wgs = std::getenv("QE_GB_AGG_WGS") ? std::atoi(std::getenv("QE_GB_AGG_WGS")) : 512;
-                const int slices = std::max(1, std::min(64, agg_wgs / P));
-                const size_t lds = (size_t)cg.part_groups * W * 8;
-                const int agg_threads = lds > 48 * 1024 ? 1024 : 256;   // a table that leaves room for one workgroup per CU: make it a big one
-                hipFunction_t f_agg = nullptr;
-                QE_HIP(hipModuleGetFunction(&f_agg, plan->kernel.module, "qe_gb_aggregate"));
-                p.agg_partial = (double *)d_tab;
-                QE_HIP(hipModuleLaunchKernel(f_agg, slices, P, 1, agg_threads, 1, 1, 0, ctx->stream, args, nullptr));
-            }
-            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-            QE_HIP(hipStreamSynchronize(ctx->stream));   // the temporaries go back to the pool when this scope ends
-        } else if (n > 0) {
-            const int64_t sub_rows = plan->geo.sub_rows();
-            const int64_t ntiles = (n + sub_rows - 1) / sub_rows;
-            const int waves = plan->geo.threads / 64;
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 4));
-            FusedParams p;
-            fill_inputs(p, batch, *plan);
-            p.agg_partial = (double *)d_tab;
-            launch_fused(ctx, *plan, p, grid);
-        }
-        QE_HIP(hipMemcpyAsync(tab.data(), d_tab, tab.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        QE_HIP(hipStreamSynchronize(ctx->stream));
-        if (n > 0) collect_time(ctx);
-        // fold the per-XCD copies into copy 0, in XCD order
-        for (int c = 1; c < copies; c++) {
-            for (int64_t g = 0; g < G; g++) {
-                unsigned long long *d = &tab[(size_t)g * W];
-                const unsigned long long *e = &tab[((size_t)c * G + g) * W];
-                if (e[0] == ~0ull) continue;
-                d[0] = std::min(d[0], e[0]);
-                for (int i = 0; i < nagg; i++) {
-                    if (e[1 + 2 * cg.cnt_src[i]] == 0) continue;
-                    if (cg.cnt_src[i] == i) d[1 + 2 * i] += e[1 + 2 * i];
-                    if (agg_fns[i] == QE_AGG_SUM || agg_fns[i] == QE_AGG_AVG) {
-                        double a, b;
-                        std::memcpy(&a, &d[2 + 2 * i], 8);
-                        std::memcpy(&b, &e[2 + 2 * i], 8);
-                        a += b;
-                        std::memcpy(&d[2 + 2 * i], &a, 8);
-                    } else if (agg_fns[i] == QE_AGG_MIN) {
-                        d[2 + 2 * i] = (unsigned long long)std::min((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
-                    } else if (agg_fns[i] == QE_AGG_MAX) {
-                        d[2 + 2 * i] = (unsigned long long)std::max((long long)d[2 + 2 * i], (long long)e[2 + 2 * i]);
-                    }
-                }
-            }
-        }
-        // groups in insertion order = ascending first row (LinkedHashMap order, GroupByAggregationOperator.kt:22)
-        std::vector<std::pair<unsigned long long, int64_t>> order;
-        for (int64_t g = 0; g < G; g++)
-            if (tab[(size_t)g * W] != ~0ull) order.emplace_back(tab[(size_t)g * W], g);
-        std::sort(order.begin(), order.end());
-        const int64_t m = (int64_t)order.size();
-        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
-        res->count = m;
-        res->capacity = m;
-        const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
-        auto upload = [&](const void *src, size_t bytes) -> void * {
-            void *d = ctx->pool.alloc(std::max<size_t>(bytes, 16));
-            if (bytes) QE_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-            return d;
-        };
-        std::vector<std::vector<unsigned long long>> keep_words;   // host staging must outlive the async copies
-        std::vector<std::vector<int32_t>> keep_codes;
-        std::vector<std::vector<double>> keep_vals;
-        int64_t stride = 1;
-        for (size_t k = 0; k < cg.keys.size(); k++) {
-            const int domain = cg.key_domain[k];
-            OutColumn oc;
-            oc.type = cg.keys[k].type;
-            oc.dict = cg.keys[k].dict;
-            oc.dict_handle.d = oc.dict;
-            std::vector<unsigned long long> valid(words, 0), bits(words, 0);
-            std::vector<int32_t> codes((size_t)std::max<int64_t>(m, 1), 0);
-            bool any_null = false;
-            for (int64_t j = 0; j < m; j++) {
-                const int code = (int)((order[j].second / stride) % (domain + 1));
-                if (code == domain) { any_null = true; continue; }
-                valid[j >> 6] |= 1ull << (j & 63);
-                codes[j] = code;
-                if (code) bits[j >> 6] |= 1ull << (j & 63);
-            }
-            oc.nullable = any_null;
-            if (oc.type == QE_BOOLEAN) {
-                keep_words.push_back(bits);
-                oc.data = upload(keep_words.back().data(), words * 8);
-            } else {
-                keep_codes.push_back(codes);
-                oc.data = upload(keep_codes.back().data(), (size_t)m * 4);
-            }
-            if (any_null) {
-                keep_words.push_back(valid);
-                oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
-            }
-            res->cols.push_back(oc);
-            stride *= (domain + 1);
-        }
-        for (int i = 0; i < nagg; i++) {
-            OutColumn oc;
-            oc.type = QE_DOUBLE;
-            std::vector<double> vals((size_t)std::max<int64_t>(m, 1), 0.0);
-            std::vector<unsigned long long> valid(words, 0);
-            bool any_null = false;
-            for (int64_t j = 0; j < m; j++) {
-                const unsigned long long *e = &tab[(size_t)order[j].second * W];
-                const unsigned long long cnt = e[1 + 2 * cg.cnt_src[i]];
-                const unsigned long long raw = e[2 + 2 * i];
-                double v = 0.0;
-                bool ok = true;
-                switch (agg_fns[i]) {
-                case QE_AGG_COUNT: v = (double)cnt; break;                       // Accumulators.kt:26-36
-                case QE_AGG_SUM: std::memcpy(&v, &raw, 8); ok = cnt != 0; break;  // :47-53 empty => null
-                case QE_AGG_AVG: std::memcpy(&v, &raw, 8); ok = cnt != 0; if (ok) v /= (double)cnt; break;
-                default: {                                                        // MIN / MAX: undo the ordered key
-                    long long key = (long long)raw;
-                    long long b = key ^ ((key >> 63) & 0x7fffffffffffffffll);
-                    std::memcpy(&v, &b, 8);
-                    ok = cnt != 0;
-                }
-                }
-                if (ok) valid[j >> 6] |= 1ull << (j & 63);
-                else { any_null = true; v = 0.0; }
-                vals[j] = v;
-            }
-            oc.nullable = any_null;
-            keep_vals.push_back(vals);
-            oc.data = upload(keep_vals.back().data(), (size_t)m * 8);
-            if (any_null) {
-                keep_words.push_back(valid);
-                oc.validity = (uint64_t *)upload(keep_words.back().data(), words * 8);
-            }
-            res->cols.push_back(oc);
-        }
-        QE_HIP(hipStreamSynchronize(ctx->stream));
-        *out = res.release();
+        *out = run_groupby_dense(ctx, batch, plan, agg_fns, nagg);
     });
 }
 

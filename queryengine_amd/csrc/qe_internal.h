@@ -263,6 +263,8 @@ struct Plan {
     ~Plan() { for (void *q : aux_dev) (void)hipFree(q); }
     mutable double last_selectivity = -1.0;   // kept / scanned rows of the last execution (picks the two-pass form)
     mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
+    mutable int64_t id_capacity = 0;          // .. of the key -> dense id table (qe_ht_build)
+    mutable bool use_ids = false;             // .. the keys did not fit the LDS table last time: resolve them to dense ids first
     int est_regs = 0;                         // register estimate of the plan's geometry (get_plan)
     bool explicit_geometry = false;           // unroll / chunk / ring were fixed through qe_options.tuning
 };
@@ -307,6 +309,7 @@ struct qe_ctx {
     // the "wide" one (16 load groups per sub-tile, 512-entry LDS rings, 2 waves per SIMD); the faster one is kept
     struct GeoChoice { int chosen = -1; int runs[2] = {0, 0}; float best_ms[2] = {1e30f, 1e30f}; bool from_cache = false; };
     std::map<const qe::Plan *, GeoChoice> geo_choice;   // plans live as long as the context: the pointer is never recycled
+    std::map<int64_t, std::shared_ptr<qe::DictData>> id_dicts;   // placeholder dictionaries of 2^k entries: the domain of a dense-id key column
     std::string source_scratch;
     // profiling of the dominant kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
