@@ -1157,7 +1157,7 @@ void append_key_columns(qe_ctx *ctx, const CodegenOutput &cg, qe_result *res, in
 qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const qe_expr *filter, const qe_expr *const *exprs,
                            const int32_t *agg_fns, int32_t nagg) {
     const CodegenOutput &cg = plan.cg;
-    const int NK = (int)cg.keys.size(), BW = 3 + NK;
+    const int NK = (int)cg.keys.size(), BW = NK == 1 ? 2 : 3 + NK;   // single-key plans: 16-byte entries {key, state | null bits | id}
     const int64_t n = batch->nrows;
     std::vector<void *> temps;
     struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
@@ -1331,8 +1331,8 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             plan.hash_capacity = C;
             const int64_t used = hc[0];
             // more than a few dozen keys: probing the LDS table costs more than resolving ids first (300 keys: 15 ms here,
-            // ~6 ms as build pass + dense LDS group-by) -- the next executions of this plan go that way
-            static const int64_t ids_from = std::getenv("QE_IDS_FROM") ? std::atoll(std::getenv("QE_IDS_FROM")) : 128;
+            // 6.6 ms as build pass + dense LDS group-by; crossover ~70 keys) -- the next executions of this plan go that way
+            static const int64_t ids_from = std::getenv("QE_IDS_FROM") ? std::atoll(std::getenv("QE_IDS_FROM")) : 64;
             if (used > ids_from && ids_allowed) plan.use_ids = true;
             unsigned long long *d_dense = (unsigned long long *)ctx->pool.alloc((size_t)std::max<int64_t>(used, 1) * W * 8);
             struct G2 { qe_ctx *c; void *p; ~G2() { c->pool.release(p); } } g2{ctx, d_dense};

@@ -305,16 +305,18 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
                 assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
 
 
-@pytest.mark.parametrize("case", ["double_specials", "int64_many", "mixed_keys", "grows"])
+@pytest.mark.parametrize("case", ["double_specials", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
     (all NaNs one group, -0.0 and 0.0 two groups), NULL is a key; groups in the reference's insertion order; few keys stay
-    in the workgroups' LDS tables, many go through the global table, which grows when more than half full."""
+    in the workgroups' LDS tables; many are resolved to dense ids first (qe_ht_build: a global table that grows when more than
+    half full) and aggregated by the dense / partitioned kernels; debug bit 131072 keeps the global-atomic form instead."""
     from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
     from queryengine_amd import engine as E
     rng = np.random.default_rng(77)
-    ctx = E.Context(device=0)
+    # debug bit 131072 keeps the global-atomic form (the fallback for more than 2^20 keys) instead of dense ids
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else [])
     I32 = DataType.INT32
     if case == "double_specials":
         n = 150_001
@@ -323,7 +325,7 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         k = Column(D, pool[rng.integers(0, len(pool), n)], rng.random(n) > 0.03)
         keys = [ColumnExpression("k", 0, D)]
         cols = [k]
-    elif case == "int64_many":
+    elif case.startswith("int64_many"):
         n = 600_011
         k = Column(I64, rng.integers(-2 ** 62, 2 ** 62, 150_000)[rng.integers(0, 150_000, n)], rng.random(n) > 0.01)
         keys = [ColumnExpression("k", 0, I64)]
