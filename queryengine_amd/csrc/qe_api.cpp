@@ -1466,9 +1466,8 @@ qe_result *run_groupby_dense(qe_ctx *ctx, const qe_batch *batch, const std::shar
             const int rec_words = 1 + cg.nvals;
             if (m_records >= (1ull << 32)) fail(QE_ERR_UNSUPPORTED, "partitioned GROUP BY: more than 2^32 records");
             p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);   // + the spare line the scatter's idle threads write
-            // The scatter keeps one partially written line open per (wave, partition).  With every CU full of waves those open
-            // lines exceed the L2s and each 16-byte record left for HBM on its own (WRITE_SIZE 2x the record bytes); a smaller
-            // grid keeps the open lines resident until they are complete.
+            // two workgroups per CU: the 64 KiB LDS stage of the tile sort lets two share a CU (one sorts and stores while the
+            // other waits for its loads)
             static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
             hipDeviceptr_t dbg = nullptr;

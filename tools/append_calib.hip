@@ -67,6 +67,9 @@ int main() {
             run<64, 16>(dst, np, steps, wg, 48);
             run<2, 16>(dst, np, steps, wg, 0);
             run<8, 16>(dst, np, steps, wg, 0);
+            run<4, 16>(dst, np, steps, wg, 0);    // 64-byte runs: half lines
+            run<12, 16>(dst, np, steps, wg, 0);   // 192 bytes: whole 64-byte sectors, not whole lines
+            run<20, 16>(dst, np, steps, wg, 0);
             run<21, 8>(dst, np, steps, wg, 0);
             run<21, 4>(dst, np, steps, wg, 0);
             run<64, 8>(dst, np, steps, wg, 0);
