@@ -305,7 +305,7 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
                 assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
 
 
-@pytest.mark.parametrize("case", ["double_specials", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows"])
+@pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
@@ -318,10 +318,12 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     # debug bit 131072 keeps the global-atomic form (the fallback for more than 2^20 keys) instead of dense ids
     ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else [])
     I32 = DataType.INT32
-    if case == "double_specials":
+    if case.startswith("double_specials"):
         n = 150_001
         pool = np.array([0.0, -0.0, 1.0, 2.5, float("nan"), float("inf"), -float("inf"), 6.0, -1.0,
                          np.frombuffer(np.uint64(0x7ff8000000000123).tobytes(), dtype=np.float64)[0]])   # a NaN with a payload
+        if case.endswith("many"):   # the same special values among 5000 ordinary keys: the dense-id path (16-byte entries)
+            pool = np.concatenate([pool, rng.normal(0, 1e6, 5000)])
         k = Column(D, pool[rng.integers(0, len(pool), n)], rng.random(n) > 0.03)
         keys = [ColumnExpression("k", 0, D)]
         cols = [k]
