@@ -16,6 +16,7 @@
 // It needs no JIT and is the general path; the fused kernel (qe_codegen.cpp) is the fast path.
 #include "qe_pernode.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <functional>
@@ -116,9 +117,23 @@ struct Exec {
         const int64_t old_n = n;
         (void)old_n;
         n = m;
+        // the row ids and every value column the old domain had gathered move to the new one in ONE launch (the positions
+        // `rel` are read once)
+        pn::GatherArgs ga{};
+        ga.idx = r;
+        ga.m = m;
+        std::vector<Buf> keep_alive;
+        auto flush = [&]() {
+            if (ga.ncols > 0) pn::gather_multi(s, ga);
+            ga.ncols = 0;
+        };
         if (ids) {
             Buf nids = alloc((size_t)std::max<int64_t>(m, 1) * 4);
-            pn::gather(s, QE_INT32, ids.get(), r, nids.get(), m);
+            ga.src[ga.ncols] = ids.get();
+            ga.dst[ga.ncols] = nids.get();
+            ga.width[ga.ncols] = 4;
+            ga.ncols++;
+            keep_alive.push_back(ids);   // the old ids stay allocated until the gather has been launched
             ids = nids;
         } else {
             ids = rel;
@@ -134,7 +149,11 @@ struct Exec {
                 pn::gather_bits(s, (const uint64_t *)v.data.get(), r, (uint64_t *)c.data.get(), m);
             } else {
                 c.data = alloc_col(v.type);
-                pn::gather(s, kernel_type(v.type), v.data.get(), r, c.data.get(), m);
+                ga.src[ga.ncols] = v.data.get();
+                ga.dst[ga.ncols] = c.data.get();
+                ga.width[ga.ncols] = (int)width_of(v.type);
+                keep_alive.push_back(v.data);   // the source stays allocated until its gather has been launched
+                if (++ga.ncols == 8) flush();
             }
             if (v.valid) {
                 c.valid = alloc_words();
@@ -142,6 +161,7 @@ struct Exec {
             }
             v = c;
         }
+        flush();
     }
 
     Buf alloc(size_t bytes) {

@@ -499,16 +499,44 @@ void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, uint32
 // words of a wave are adjacent and so are their output ranges, so step i of the walk is one store instruction with every
 // lane that still has a bit active, all within a few hundred bytes.  (One wave per word -- lanes = bits -- issued a store
 // instruction with ~3 active lanes per word at 5 % selectivity: 1.43 ms per 1 B rows.)
+// Round 2: when the wave's 64 words hold at most 1024 kept rows (the usual case below ~25 %) the row ids first meet in a 4 KiB
+// LDS buffer of the wave and leave in whole 256-byte store instructions: the direct form issues up to max-bits-per-word store
+// instructions of 64 lanes x 4 bytes spread over ~12 lines each (0.27 ms per 1 B rows at 10 %).
 __global__ void __launch_bounds__(256) k_expand_indices(const u64 *v, const u64 *k, i64 n, const u32 *word_offsets,
                                                         u32 *indices, i64 nw) {
+    __shared__ u32 s_buf[4][1024];
+    u32 *buf = s_buf[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
-        u64 x = keep_word(v, k, w, n);
-        u32 pos = word_offsets[w];
+    const i64 nw_pad = (nw + 63) & ~63ll;   // whole waves: the wave-level steps below need every lane
+    for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < nw_pad; w += stride) {
+        u64 x = w < nw ? keep_word(v, k, w, n) : 0ull;
+        u32 pos = w < nw ? word_offsets[w] : 0u;
         const u32 base = (u32)(w * 64);
-        while (x != 0) {
-            indices[pos++] = base + (u32)__builtin_ctzll(x);
-            x &= x - 1;
+        const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)pos);                                   // the wave's words are adjacent
+        const u32 cnt = (u32)__popcll(x);
+        // total of the wave: an inclusive scan is not needed, offsets are already exclusive -- last valid lane's pos + cnt
+        u32 endpos = pos + cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u32 t = (u32)__shfl_xor((int)endpos, o, 64);
+            endpos = t > endpos ? t : endpos;
+        }
+        const u32 total = endpos - first;
+        if (total <= 1024u) {
+            u32 q = pos - first;
+            while (x != 0) {
+                buf[q++] = base + (u32)__builtin_ctzll(x);
+                x &= x - 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (u32 j = (u32)lane; j < total; j += 64u) indices[first + j] = buf[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            while (x != 0) {
+                indices[pos++] = base + (u32)__builtin_ctzll(x);
+                x &= x - 1;
+            }
         }
     }
 }
