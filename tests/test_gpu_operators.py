@@ -250,6 +250,48 @@ def test_group_by_partitioned_sizes_around_tiles_and_chunks(n, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["dictionary_100k", "double_100k"])
+def test_group_by_full_size_properties(kind, oracle):
+    """1 B rows through the partitioned passes (100 000 dictionary keys) and through the dense-id path (100 000 distinct DOUBLE
+    keys): properties that do not need a second engine -- every key is a group, COUNT adds up to the rows the filter keeps (an
+    independent filter + COUNT aggregate), SUM adds up to the independent SUM within the reassociation bound, the first
+    groups are the keys of the first rows in their order of first appearance (the oracle walks that window row by row)."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import engine as E
+    from queryengine_amd.workloads import GenColumn
+    n, nkeys = 1_000_000_000, 100_000
+    ctx = E.Context(device=0)
+    if kind == "dictionary_100k":
+        d = ["k%06d" % i for i in range(nkeys)]
+        gen = [GenColumn("k", S, N.GEN_DICT_MOD, 0, modulus=nkeys, dictionary=d), GenColumn("v", D, N.GEN_F64_UNIT, 1)]
+        K = ColumnExpression("k", 0, S)
+    else:
+        gen = [GenColumn("k", D, N.GEN_F64_MOD, 0, modulus=nkeys), GenColumn("v", D, N.GEN_F64_UNIT, 1)]
+        K = ColumnExpression("k", 0, D)
+    V = ColumnExpression("v", 1, D)
+    batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in gen], n)
+    flt = FunctionExpression(Function.CMP_LT, [V, NumericLiteralExpression(0.25)], B)
+    cf = ctx.compile(flt)
+    for rep in range(2):   # DOUBLE keys: the first execution finds out that the keys do not fit LDS, the second starts with ids
+        res = E.filter_groupby(ctx, batch, cf, [ctx.compile(K)], [ctx.compile(V), ctx.compile(V)], [oracle.SUM, oracle.COUNT])
+        cols, ngroups = res.to_columns(), res.count
+        res.free()
+        assert ngroups == nkeys
+        counts, sums = cols[2].data, cols[1].data
+        (tot_sum, tot_cnt), nsel = E.filter_aggregate(ctx, batch, cf, [ctx.compile(V), ctx.compile(V)], [oracle.SUM, oracle.COUNT])
+        assert int(counts.sum()) == int(tot_cnt) == nsel and abs(nsel / n - 0.25) < 1e-3
+        assert abs(float(sums.sum()) - tot_sum) <= 1e-9 * tot_sum
+        assert counts.min() > 0.5 * nsel / nkeys and counts.max() < 2 * nsel / nkeys          # uniform keys
+        # insertion order: the groups the oracle finds in the first rows come first, in the same order
+        m = 20_000
+        host = [batch.column_to_host(j, 0, m, dictionary=gen[j].dictionary) for j in range(batch.ncols)]
+        want = oracle.filter_groupby(host, flt, [K], [V, V], [oracle.SUM, oracle.COUNT], oracle.BYTECODE_COMPILER)
+        head = [cols[0].value(i) for i in range(len(want))]
+        assert head == [w[0] for w in want]
+    batch.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("path", ["lds", "partitioned", "global_atomics"])
 def test_group_by_counter_sharing_with_mixed_nullability(path, oracle):
     """Aggregates over non-nullable inputs share ONE row counter per group, nullable ones keep their own: every order
