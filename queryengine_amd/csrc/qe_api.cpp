@@ -615,6 +615,13 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         in.geo.threads = 1024;   // the table fits ONE workgroup's LDS: 16 waves per CU share it (see table_in_lds)
         plan->cg = generate_fused_source(in);
     }
+    if (plan->cg.partitioned && plan->cg.nparts > 128 && ctx->opts.tuning[0] == 0 && in.geo.threads == 256 &&
+        8 + plan->cg.part_shift + 13 <= 32 && (size_t)8 * in.geo.sub_rows() * (1 + plan->cg.nvals) * 8 <= 128 * 1024) {
+        // many partitions: a tile of 8 waves (8 Ki rows, one workgroup per CU) holds twice the records per partition, so the
+        // whole-line padding of the scatter pass costs half as much (1 M keys: 45 % -> 22 % more records)
+        in.geo.threads = 512;
+        plan->cg = generate_fused_source(in);
+    }
     if (plan->cg.hashed && ctx->opts.tuning[1] == 0 && in.geo.unroll > 4) {
         in.geo.unroll = 4;   // hashed group-by: the key words of 2 * U rows live in registers next to the inputs; it is bound by atomics, not by loads in flight
         plan->cg = generate_fused_source(in);
@@ -1469,7 +1476,7 @@ qe_result *run_groupby_dense(qe_ctx *ctx, const qe_batch *batch, const std::shar
             // two workgroups per CU: the 64 KiB LDS stage of the tile sort lets two share a CU (one sorts and stores while the
             // other waits for its loads)
             static const int scatter_wgs = std::getenv("QE_GB_SCATTER_WGS_PER_CU") ? std::atoi(std::getenv("QE_GB_SCATTER_WGS_PER_CU")) : kScatterWgsPerCu;
-            const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * std::max(1, scatter_wgs)));
+            const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * (plan->geo.threads >= 512 ? 1 : std::max(1, scatter_wgs))));
             hipDeviceptr_t dbg = nullptr;
             size_t dbg_bytes = 0;
             if (ctx->opts.tuning[5] & 64) {
