@@ -1851,14 +1851,18 @@ int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, doub
         launch_stream_read(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8));
         QE_HIP(hipStreamSynchronize(ctx->stream));
         double best = 1e30;
-        for (int r = 0; r < reps; r++) {
-            QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-            launch_stream_read(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8));
-            QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-            QE_HIP(hipStreamSynchronize(ctx->stream));
-            float ms = 0.f;
-            QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            best = std::min(best, (double)ms);
+        // the achievable read rate depends on how many waves stream: 8 per CU (2 workgroups) reach ~7 TB/s where 32 reach ~6.3
+        // (tools/copy_calib.hip) -- the calibration reports the best of 2 / 4 / 8 workgroups per CU
+        for (int wgs : {2, 4, 8}) {
+            for (int r = 0; r < reps; r++) {
+                QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+                launch_stream_read(ctx->stream, buf, nbytes, (unsigned long long *)(ctx->d_ctrl + 8), wgs);
+                QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+                QE_HIP(hipStreamSynchronize(ctx->stream));
+                float ms = 0.f;
+                QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+                best = std::min(best, (double)ms);
+            }
         }
         *out_gbps = (double)(nbytes / 16 * 16) / (best * 1e-3) / 1e9;
     });

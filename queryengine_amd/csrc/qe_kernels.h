@@ -12,7 +12,7 @@ void launch_generate(hipStream_t s, const qe_gen_spec &spec, uint64_t seed, int6
 // bytes (0/1 per row) -> bitmap words (row i = word i>>6 bit i&63)
 void launch_pack_bytes(hipStream_t s, const uint8_t *bytes, int64_t n, uint64_t *words);
 // plain streaming read of nbytes (16 B per lane), result folded into sink[0] so nothing is elided
-void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink);
+void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, int wgs_per_cu = 8);
 
 // read stream + a trickle of writes (one 512-byte block per wave every `write_every` read iterations of 8 KiB)
 void launch_stream_read_write(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, void *dst,

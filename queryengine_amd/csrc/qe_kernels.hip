@@ -97,19 +97,21 @@ void launch_pack_bytes(hipStream_t s, const uint8_t *bytes, int64_t n, uint64_t 
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-// Read-only stream: 16 B per lane per load, 8 independent loads in flight per lane.
+// Read-only stream: a wave reads 4 KiB contiguous per step (4 loads of 16 B per lane in flight), waves stride over the buffer
+// (tools/copy_calib.hip measured this shape at 7.0 - 7.4 TB/s with 8 waves per CU; 8 strided loads per lane reached 6.3 - 6.5).
 __global__ void __launch_bounds__(256) stream_read_kernel(const u64x2 *src, i64 nvec, u64 *sink) {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (i64)gridDim.x * (blockDim.x >> 6);
+    const i64 nsteps = nvec / 256;
     u64 acc = 0;
-    for (; i + 7 * stride < nvec; i += 8 * stride) {
-        u64x2 v[8];
+    for (i64 it = wave; it < nsteps; it += nwaves) {
+        u64x2 v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + (it * 4 + j) * 64 + lane);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc ^= v[j].x ^ v[j].y;
+        for (int j = 0; j < 4; ++j) acc ^= v[j].x ^ v[j].y;
     }
-    for (; i < nvec; i += stride) {
+    for (i64 i = nsteps * 256 + wave * 64 + lane; i < nvec; i += nwaves * 64) {
         const u64x2 v = __builtin_nontemporal_load(src + i);
         acc ^= v.x ^ v.y;
     }
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) stream_read_sparse_kernel(const u64x2 *sr
     if (acc == 0x0123456789abcdefull) sink[0] = acc;
 }
 
-void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink) {
+void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned long long *sink, int wgs_per_cu) {
     const i64 nvec = nbytes / 16;
     if (nvec <= 0) return;
     static const int sparse_pct = std::getenv("QE_CALIB_SPARSE_PCT") ? std::atoi(std::getenv("QE_CALIB_SPARSE_PCT")) : -1;
@@ -233,7 +235,7 @@ void launch_stream_read(hipStream_t s, const void *src, int64_t nbytes, unsigned
         }
     }
     else
-        hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
+        hipLaunchKernelGGL(stream_read_kernel, dim3(256 * (wgs_per_cu > 0 ? wgs_per_cu : 8)), dim3(256), 0, s, (const u64x2 *)src, nvec, (u64 *)sink);
 }
 
 // ---- partitioned group-by -------------------------------------------------------------------------------------------
