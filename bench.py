@@ -296,6 +296,13 @@ def main():
         except Exception:
             pass
         dense = args.exec_mode == "fused" and wl.filter is not None and nout >= 0.12 * nrows
+        geometry = None
+        if args.exec_mode == "fused":   # which of the plan's two kernel geometries the measured choice kept (and whether it came from the JIT cache)
+            try:
+                g_, cached_ = E.chosen_geometry(ctx, batch, cf, cp)
+                geometry = {"chosen": {-1: "undecided", 0: "default", 1: "wide"}.get(g_, str(g_)), "from_jit_cache": cached_}
+            except Exception:
+                geometry = None
         out = {
             "metric": "rows/sec filter+project over int64/f64 batch; achieved HBM GB/s in roofline",
             "value": world * nrows * args.steps / dt_max,
@@ -319,6 +326,7 @@ def main():
                          "kernel": ("qe_fused (dense single-pass form, chosen from selectivity 0.12 on)" if dense else
                                     "qe_fused (LDS-ring single-pass form)" if args.exec_mode == "fused" else "per-node kernels"),
                          "kernel_ms": kernel_ms, "kernel_ms_median": median(kern_ms), "kernel_ms_min": min(kern_ms) if kern_ms else None,
+                         "geometry": geometry,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes (every input column in full + output rows) / kernel time; "
                                  "the kernel loads later filter / projection columns only for rows still alive (late "
                                  "materialisation), so measured HBM traffic can be BELOW the algorithmic bytes: frac_moved is "
