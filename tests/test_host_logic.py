@@ -337,3 +337,28 @@ def test_dense_single_pass_kernel_is_generated_and_compiles(native_lib, tmp_path
         assert "qe_conj0(" not in src and "QE_SUBS_PER_CHUNK 1u" in src       # every load up front, chunk == sub-tile
         E.prepare(ctx, batch, cf, cp)      # compiles the default, the wide AND the dense kernel
     ctx.close()
+
+
+def test_group_by_plans_generate_and_compile_without_gpu(native_lib, tmp_path):
+    """Every group-by form is generated and hiprtc-compiled on a planning-only context: the LDS-privatised table (incl. the
+    1024-thread variant for tables up to 144 KiB), the partitioned passes (4-wave tiles, 8-wave tiles past 128 partitions,
+    several record values, nullable aggregate inputs) and the hashed form with its id build pass (one key: 16-byte entries;
+    several keys).  A compile error in any generated kernel fails here, before a GPU is involved."""
+    from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
+    from queryengine_amd import Column, DataType
+    ctx = E.Context(device=None, jit_cache_dir=str(tmp_path))
+    S, D, I64, B = DataType.STRING, DataType.DOUBLE, DataType.INT64, DataType.BOOLEAN
+    for nkeys in (10, 2500, 100_000, 1_000_000):
+        d = ["k%07d" % i for i in range(nkeys)]
+        cols = [Column(S, np.zeros(2, dtype=np.int32), None, d), Column(D, np.zeros(2), np.array([True, False])), Column(I64, np.zeros(2, dtype=np.int64))]
+        batch = E.DeviceBatch.describe(ctx, cols)
+        K, X, Y = ColumnExpression("k", 0, S), ColumnExpression("x", 1, D), ColumnExpression("y", 2, I64)
+        flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(5.0)], B)
+        for f, exprs, aggs in ((None, [Y, Y], [N.AGG_SUM, N.AGG_COUNT]), (flt, [X, Y, X], [N.AGG_SUM, N.AGG_MAX, N.AGG_AVG])):
+            E.prepare_groupby(ctx, batch, ctx.compile(f) if f is not None else None, [ctx.compile(K)], [ctx.compile(e) for e in exprs], aggs)
+    cols = [Column(D, np.zeros(2), np.array([True, False])), Column(I64, np.zeros(2, dtype=np.int64)), Column(D, np.zeros(2))]
+    batch = E.DeviceBatch.describe(ctx, cols)
+    K1, K2, V = ColumnExpression("a", 0, D), ColumnExpression("b", 1, I64), ColumnExpression("v", 2, D)
+    E.prepare_groupby(ctx, batch, None, [ctx.compile(K1)], [ctx.compile(V), ctx.compile(V)], [N.AGG_MIN, N.AGG_MAX])
+    E.prepare_groupby(ctx, batch, None, [ctx.compile(K1), ctx.compile(K2)], [ctx.compile(V)], [N.AGG_SUM])
+    ctx.close()
