@@ -465,7 +465,7 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         e.dict = c.dict;
         x.env.push_back(e);          // not gathered yet
     }
-    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) {
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [](qe_result *r) {
         for (auto &c : r->cols) {
             c.hold_data.reset();
             c.hold_valid.reset();
