@@ -39,6 +39,7 @@ struct Vec {
     std::shared_ptr<DictData> dict;
     bool is_str_lit = false;
     std::string lit;
+    bool indexed = false;  // data = the BATCH column, to be read through the current domain's row ids (selection vector)
 };
 
 size_t width_of(int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 8 : 4; }
@@ -52,6 +53,9 @@ struct Exec {
     std::vector<Vec> base;       // the batch's columns (full domain)
     std::vector<Vec> env;        // columns of the current domain; data == null: not gathered for it yet
     Buf ids;                     // u32 batch row ids of the current domain's rows (null: the domain is the whole batch)
+    // batch columns whose ONLY remaining use is as a direct operand of an arithmetic node of the projections: the node reads
+    // them through the row ids (a selection vector) instead of a gathered copy that is written once and read once
+    std::vector<char> through_ids;
     int ieee;
 
     // column j in the current domain: gathered from the batch when a node first needs it here
@@ -95,6 +99,7 @@ struct Exec {
         };
         for (size_t j = 0; j < env.size(); j++) {
             if (!cols[j] || env[j].data || base[j].type == QE_BOOLEAN) continue;
+            if (j < through_ids.size() && through_ids[j]) continue;
             Vec &v = env[j];
             v.type = base[j].type;
             v.dict = base[j].dict;
@@ -177,6 +182,7 @@ struct Exec {
         o.ptr = v.scalar ? nullptr : v.data.get();
         o.f = v.f;
         o.i = v.i;
+        o.idx = v.indexed ? (const uint32_t *)ids.get() : nullptr;
         return o;
     }
 
@@ -265,7 +271,17 @@ struct Exec {
             return r;
         }
         case QE_FN_ADD: case QE_FN_SUB: case QE_FN_MUL: case QE_FN_DIV: case QE_FN_MOD: {
-            Vec a = eval(e, nd.ops[0]), b = eval(e, nd.ops[1]);
+            auto operand = [&](int oid) -> Vec {
+                const Node &on = e.nodes[oid];
+                if (on.kind == N_COLUMN && ids && on.col >= 0 && on.col < (int)through_ids.size() && through_ids[(size_t)on.col] &&
+                    !env[(size_t)on.col].data && base[(size_t)on.col].type == on.type) {
+                    Vec v = base[(size_t)on.col];   // the batch column itself (non-owning), read as column[ids[j]]
+                    v.indexed = true;
+                    return v;
+                }
+                return eval(e, oid);
+            };
+            Vec a = operand(nd.ops[0]), b = operand(nd.ops[1]);
             if (a.scalar && b.scalar) a = materialize(a);
             r.valid = and_valid(a.valid, b.valid);
             const int op = nd.fn == QE_FN_ADD ? pn::A_ADD : nd.fn == QE_FN_SUB ? pn::A_SUB : nd.fn == QE_FN_MUL ? pn::A_MUL
@@ -515,6 +531,26 @@ qe_result *run_per_node(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filte
         // 3. the projections' columns that the final domain has not seen yet: one gather launch
         std::vector<char> used(x.env.size(), 0);
         for (int32_t i = 0; i < nproj; i++) collect_columns(projs[i]->e, used);
+        // a value column that the projections use exactly once, as a direct operand of an arithmetic node, is not gathered:
+        // the node reads it through the row ids (cfg 2: `a + b` -- 0.8 GB less written and 0.8 GB less read per 1 B rows)
+        if (x.ids) {
+            std::vector<int> refs(x.env.size(), 0), arith_refs(x.env.size(), 0);
+            for (int32_t i = 0; i < nproj; i++) {
+                const Expr &pe = projs[i]->e;
+                for (const Node &nd : pe.nodes) {
+                    if (nd.kind == N_COLUMN && nd.col >= 0 && nd.col < (int)refs.size()) refs[(size_t)nd.col]++;
+                    if (nd.kind == N_FN && (nd.fn == QE_FN_ADD || nd.fn == QE_FN_SUB || nd.fn == QE_FN_MUL || nd.fn == QE_FN_DIV || nd.fn == QE_FN_MOD))
+                        for (int op : nd.ops) {
+                            const Node &on = pe.nodes[(size_t)op];
+                            if (on.kind == N_COLUMN && on.col >= 0 && on.col < (int)refs.size()) arith_refs[(size_t)on.col]++;
+                        }
+                }
+            }
+            x.through_ids.assign(x.env.size(), 0);
+            for (size_t j = 0; j < x.env.size(); j++)
+                x.through_ids[j] = refs[j] == 1 && arith_refs[j] == 1 && !x.base[j].valid && !x.env[j].data &&
+                                   (x.base[j].type == QE_DOUBLE || x.base[j].type == QE_INT64 || x.base[j].type == QE_INT32);
+        }
         x.prefetch(used);
     }
     // 4. projections over the (compacted) domain

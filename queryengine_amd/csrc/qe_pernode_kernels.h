@@ -15,6 +15,9 @@ struct Opnd {
     const void *ptr;
     double f;
     long long i;
+    // selection vector: element j of the operand is ptr[idx[j]] (a batch column read through the row ids of a narrowed domain,
+    // instead of a gathered copy); null = ptr[j]
+    const uint32_t *idx = nullptr;
 };
 
 // type codes follow QE_* (QE_DOUBLE=1, QE_INT64=3, QE_INT32=4; STRING codes are handled as INT32)

@@ -22,13 +22,14 @@ typedef unsigned int u32;
 template <typename T> struct Ld {
     const T *p;
     T s;
-    __device__ __forceinline__ T operator[](i64 i) const { return p ? p[i] : s; }
+    const u32 *idx;   // selection vector (Opnd::idx) or null
+    __device__ __forceinline__ T operator[](i64 i) const { return p ? (idx ? p[idx[i]] : p[i]) : s; }
 };
 
 template <typename T> static Ld<T> mk(const Opnd &o);
-template <> Ld<double> mk<double>(const Opnd &o) { return Ld<double>{(const double *)o.ptr, o.f}; }
-template <> Ld<i64> mk<i64>(const Opnd &o) { return Ld<i64>{(const i64 *)o.ptr, (i64)o.i}; }
-template <> Ld<int> mk<int>(const Opnd &o) { return Ld<int>{(const int *)o.ptr, (int)o.i}; }
+template <> Ld<double> mk<double>(const Opnd &o) { return Ld<double>{(const double *)o.ptr, o.f, o.idx}; }
+template <> Ld<i64> mk<i64>(const Opnd &o) { return Ld<i64>{(const i64 *)o.ptr, (i64)o.i, o.idx}; }
+template <> Ld<int> mk<int>(const Opnd &o) { return Ld<int>{(const int *)o.ptr, (int)o.i, o.idx}; }
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 16384) {
     int64_t b = (n + per_block - 1) / per_block;
@@ -78,6 +79,11 @@ template <typename T> using Vec2 = typename V2<T>::type;
 
 template <typename T> __device__ __forceinline__ Pair<T> ld2(const Ld<T> &a, i64 pair) {
     if (!a.p) return Pair<T>{a.s, a.s};
+    if (a.idx) {   // through the selection vector: the two row ids in one 8-byte load, then two gathers
+        typedef u32 U2 __attribute__((ext_vector_type(2)));
+        const U2 r = __builtin_nontemporal_load((const U2 *)a.idx + pair);
+        return Pair<T>{a.p[r.x], a.p[r.y]};
+    }
     const Vec2<T> v = __builtin_nontemporal_load((const Vec2<T> *)a.p + pair);
     return Pair<T>{v.x, v.y};
 }
