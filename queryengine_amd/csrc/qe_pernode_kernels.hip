@@ -285,10 +285,78 @@ __global__ void __launch_bounds__(256) k_cmp(Ld<T> a, Ld<T> b, u64 *out, i64 n) 
     }
 }
 
+// Variant without cross-lane traffic: lane l takes rows l and l + 64 of every 128-row group (two loads of one element each
+// instead of one load of two), so the two ballots ARE the group's two bitmap words -- no ds_bpermute, no per-lane shifts.
+template <typename T, int CMP, int IEEE, int K>
+__global__ void __launch_bounds__(256) k_cmp_rows(Ld<T> a, Ld<T> b, u64 *out, i64 n) {
+    const int lane = threadIdx.x & 63;
+    const i64 cstride = (i64)gridDim.x * (blockDim.x >> 6);
+    const i64 nchunks = (n + 511) >> 9, nfull = n >> 9;
+    const i64 nw = (n + 63) >> 6;
+    for (i64 c0 = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c0 < nchunks; c0 += K * cstride) {
+        bool r0[K][4], r1[K][4];
+        if (c0 + (K - 1) * cstride < nfull) {
+            T x0[K][4], x1[K][4], y0[K][4], y1[K][4];
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i64 r = ((c0 + q * cstride) * 4 + j) * 128 + lane;
+                    x0[q][j] = a[r]; x1[q][j] = a[r + 64];
+                    y0[q][j] = b[r]; y1[q][j] = b[r + 64];
+                }
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r0[q][j] = CmpOp<T, CMP, IEEE>::apply(x0[q][j], y0[q][j]);
+                    r1[q][j] = CmpOp<T, CMP, IEEE>::apply(x1[q][j], y1[q][j]);
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const i64 r = ((c0 + q * cstride) * 4 + j) * 128 + lane;
+                    bool t0 = false, t1 = false;
+                    if (r < n) t0 = CmpOp<T, CMP, IEEE>::apply(a[r], b[r]);
+                    if (r + 64 < n) t1 = CmpOp<T, CMP, IEEE>::apply(a[r + 64], b[r + 64]);
+                    r0[q][j] = t0; r1[q][j] = t1;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const i64 c = c0 + q * cstride;
+            u64 mine = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 w0 = __ballot(r0[q][j]), w1 = __ballot(r1[q][j]);
+                if (lane == 2 * j) mine = w0;
+                if (lane == 2 * j + 1) mine = w1;
+            }
+            if (lane < 8 && c * 8 + lane < nw) out[c * 8 + lane] = mine;
+        }
+    }
+}
+
 template <typename T, int IEEE, int K> static void cmp_tk(hipStream_t s, int cmp, const Opnd &a, const Opnd &b, u64 *out, int64_t n) {
     static const int wgs_per_cu = getenv("QE_PN_CMP_WGS") ? atoi(getenv("QE_PN_CMP_WGS")) : 4;   // 16 waves per CU: 1.25 - 1.28 ms per 8 GB column; 32 waves 1.43 ms
     const int g = grid_for((n + 511) / 512, 4, 256 * wgs_per_cu);   // 4 waves per workgroup, K 512-row chunks per wave and step
     Ld<T> la = mk<T>(a), lb = mk<T>(b);
+    // 4-byte columns (INT32, dictionary codes) take the row-per-lane form: k_cmp is bound by its per-group work, not by bytes
+    // (~800 G rows/s for 8- and 4-byte columns alike), and without the cross-lane merge an int column runs 0.77 -> 0.43 ms per
+    // 600 M rows; for 8-byte columns the two 8-byte loads cost more than the merge saves (1.51 against 1.22 ms per 1 B rows)
+    if (sizeof(T) == 4) {
+        switch (cmp) {
+        case C_LT: hipLaunchKernelGGL((k_cmp_rows<T, C_LT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        case C_LE: hipLaunchKernelGGL((k_cmp_rows<T, C_LE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        case C_GE: hipLaunchKernelGGL((k_cmp_rows<T, C_GE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        case C_GT: hipLaunchKernelGGL((k_cmp_rows<T, C_GT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        case C_EQ: hipLaunchKernelGGL((k_cmp_rows<T, C_EQ, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        default: hipLaunchKernelGGL((k_cmp_rows<T, C_NE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
+        }
+        return;
+    }
     switch (cmp) {
     case C_LT: hipLaunchKernelGGL((k_cmp<T, C_LT, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
     case C_LE: hipLaunchKernelGGL((k_cmp<T, C_LE, IEEE, K>), dim3(g), dim3(256), 0, s, la, lb, out, (i64)n); break;
