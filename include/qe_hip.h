@@ -234,8 +234,11 @@ int32_t qe_filter_aggregate(qe_ctx *ctx, const qe_batch *batch, const qe_expr *f
  * (operator/GroupByAggregationOperator.kt:21-49).  The result has nkeys key columns followed by nagg DOUBLE
  * aggregate columns (NULL for an empty MIN/MAX/SUM/AVG, COUNT as a double), one row per group, in INSERTION
  * order of the groups (LinkedHashMap, :22; pinned by T/evaluator/QueryTest.kt:25-30); NULL is a key value.
- * Keys must be STRING (dictionary) or BOOLEAN expressions with at most 2^20 combinations.  SUM/AVG use native
- * f64 atomics: exact when every partial sum is representable, otherwise order dependent in the last bits. */
+ * Keys are expressions of any type -- the reference groups on the boxed key tuple (:33-37; Tripdata.kt:27-31 groups by a
+ * DOUBLE column): STRING (dictionary) / BOOLEAN keys with at most 2^20 combinations index a dense table; DOUBLE / INT64 /
+ * INT32 keys (Double.equals: all NaNs one group, -0.0 and 0.0 two) and larger combinations are hashed.
+ * SUM/AVG use native f64 atomics: exact when every partial sum is representable, otherwise order dependent in the last
+ * bits. */
 int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                           const qe_expr *const *keys, int32_t nkeys,
                           const qe_expr *const *exprs, const int32_t *agg_fns, int32_t nagg, qe_result **out);
