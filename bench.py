@@ -344,17 +344,22 @@ def main():
     import threading
 
     def give_up():
+        # the line goes out first (it carries gather.error), then the process leaves NON-ZERO: a collective that hung must
+        # not look like a clean run to whoever keys on the exit code
         if rank == 0 and out is not None:
             out["gather"] = {"error": f"timeout: the exchange did not finish within {GATHER_TIMEOUT_S} s"}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     watchdog = threading.Timer(GATHER_TIMEOUT_S, give_up)
     watchdog.daemon = True
     watchdog.start()
     # the materialising exchange (cfg 5: "with and without the RCCL gather"); never part of `value`
     gather_info = None
-    if (args.gather or world > 1) and not args.no_gather and not args.profile_run and not rehearsal:
+    # a rehearsal (N ranks on ONE GPU) runs the exchange only when the caller names a transport that accepts several ranks
+    # per device (QE_RCCL_LIBRARY; RCCL itself refuses that)
+    exchange_possible = not rehearsal or world == 1 or bool(os.environ.get("QE_RCCL_LIBRARY"))
+    if (args.gather or world > 1) and not args.no_gather and not args.profile_run and exchange_possible:
         try:
             from queryengine_amd import distributed as QD
             if world > 1:
@@ -363,7 +368,8 @@ def main():
                 ctx.comm_init(1, 0, ctx.comm_unique_id())
             gather_info = QD.time_gather(ctx, batch, cf, cp, world, rank)
             if world > 1:
-                tg = torch.tensor([gather_info["ms"], gather_info["scan_plus_gather_ms"]], dtype=torch.float64, device="cuda")
+                tg = torch.tensor([gather_info["ms"], gather_info["scan_plus_gather_ms"]], dtype=torch.float64,
+                                  device="cpu" if rehearsal else "cuda")
                 dist.all_reduce(tg, op=dist.ReduceOp.MAX)
                 gather_info["ms"], gather_info["scan_plus_gather_ms"] = float(tg[0].item()), float(tg[1].item())
             gather_info["rows_per_s_with_gather"] = world * nrows / (gather_info["scan_plus_gather_ms"] * 1e-3)
@@ -377,7 +383,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:   # the line is out: a teardown that hangs after a failed exchange must not hold the job
         sys.stdout.flush()
-        late = threading.Timer(60, lambda: os._exit(0))
+        late = threading.Timer(60, lambda: os._exit(4))     # the line is out, but a teardown that hangs is not a clean exit
         late.daemon = True
         late.start()
     batch.free()

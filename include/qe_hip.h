@@ -294,7 +294,13 @@ int32_t qe_comm_rank(const qe_ctx *ctx);       /* -1 without a communicator */
 int32_t qe_comm_nranks(const qe_ctx *ctx);     /* 0 without a communicator */
 void qe_comm_destroy(qe_ctx *ctx);             /* also done by qe_ctx_destroy */
 /* Collective.  On `root`, *out = the concatenation of every rank's result in rank order (free with qe_result_free);
- * on the other ranks *out = NULL.  `local` stays owned by the caller. */
+ * on the other ranks *out = NULL.  `local` stays owned by the caller.
+ * Every rank must hold a result of the same shape (same plan): column count and types are compared on every rank, and a
+ * STRING column must carry THE SAME DICTIONARY (same entries, same order) on every rank -- codes travel, not strings, and
+ * the root labels them with its own dictionary.  A host that parses each shard's text separately (qe_csv_parse_file per
+ * rank) gets a first-appearance dictionary per shard and must pin ONE shared dictionary instead.  A mismatch is
+ * QE_ERR_INVALID_ARG on EVERY rank (the fingerprints travel in the header all-gather), as is a schema mismatch; a rank that
+ * cannot allocate its buffers makes the call fail on every rank before any transfer starts (QE_ERR_OOM). */
 int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out);
 /* Collective, small control data (aggregate partials, counts): recv gets nranks * nbytes host bytes in rank order.
  * Aggregations over a sharded table fold the per-GPU partials in rank order on the host. */

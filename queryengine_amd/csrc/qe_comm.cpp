@@ -38,9 +38,9 @@ struct RcclApi {
 };
 constexpr int kNcclUint8 = 1;   // rccl.h: ncclUint8 = 1
 
-static RcclApi &rccl() {
-    static RcclApi api;
-    if (api.handle) return api;
+static RcclApi load_rccl() {
+    RcclApi api;
+    // QE_RCCL_LIBRARY: another library with the same nine entry points (a site's own RCCL build; the test suite's transport)
     const char *names[] = {std::getenv("QE_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     std::string tried;
@@ -69,6 +69,12 @@ static RcclApi &rccl() {
     return api;
 }
 
+// initialised once, under the language's own lock; a failed load throws and is retried by the next call
+static RcclApi &rccl() {
+    static RcclApi api = load_rccl();
+    return api;
+}
+
 static void nccl_check(int r, const char *what) {
     if (r == 0) return;
     const char *msg = rccl().GetErrorString ? rccl().GetErrorString(r) : "?";
@@ -79,24 +85,69 @@ static void nccl_check(int r, const char *what) {
 static size_t width_of(int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 8 : (t == QE_INT32 || t == QE_STRING) ? 4 : 0; }
 static size_t words_of(int64_t n) { return (size_t)((n + 63) / 64); }
 
+// Fingerprint of a dictionary: STRING columns travel as raw codes, so every rank must hold the SAME dictionary (same
+// entries in the same order) or the root would decode a peer's codes to the wrong strings.
+static uint64_t dict_fingerprint(const DictData *d) {
+    if (!d) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *c = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 1099511628211ull;
+    };
+    const uint64_t n = d->entries.size();
+    mix(&n, 8);
+    for (const std::string &e : d->entries) {
+        const uint64_t len = e.size();
+        mix(&len, 8);
+        mix(e.data(), e.size());
+    }
+    return h ? h : 1;
+}
+
 // header every rank contributes to the all-gather: its row count and the shape of its result
+constexpr int kGatherMaxCols = 16;
 struct GatherHeader {
     int64_t count;
     int32_t ncols;
     uint32_t validity_mask;    // bit c: column c carries a validity bitmap on this rank
     uint64_t type_sig;         // 4 bits per column: the column types must agree on every rank
+    uint64_t dict_fp[kGatherMaxCols];   // STRING columns: dict_fingerprint of the column's dictionary (0 otherwise)
 };
 
-static GatherHeader header_of(const qe_result *r) {
+static GatherHeader header_of(const qe_result *r, bool with_dicts = false) {
     GatherHeader h{};
     h.count = r->count;
     h.ncols = (int32_t)r->cols.size();
-    for (size_t c = 0; c < r->cols.size(); c++) {
+    for (size_t c = 0; c < r->cols.size() && c < (size_t)kGatherMaxCols; c++) {
         if (r->cols[c].validity) h.validity_mask |= 1u << c;
         h.type_sig |= (uint64_t)(r->cols[c].type & 15) << (4 * c);
+        if (with_dicts && r->cols[c].type == QE_STRING) h.dict_fp[c] = dict_fingerprint(r->cols[c].dict.get());
     }
     return h;
 }
+
+// ncclGroupStart .. ncclGroupEnd that is closed on every path: an exception between the two must not leave the thread's
+// group open (every later collective of the thread would be queued into it and never run)
+struct RcclGroup {
+    RcclApi &nc;
+    bool open = false;
+    explicit RcclGroup(RcclApi &api) : nc(api) {
+        const int r = nc.GroupStart();
+        if (r != 0) fail(QE_ERR_COMM, "ncclGroupStart failed (" + std::to_string(r) + ")");
+        open = true;
+    }
+    void end() {
+        open = false;
+        const int r = nc.GroupEnd();
+        if (r != 0) {
+            const char *msg = nc.GetErrorString ? nc.GetErrorString(r) : nullptr;
+            fail(QE_ERR_COMM, std::string("ncclGroupEnd failed: ") + (msg ? msg : "?") + " (" + std::to_string(r) + ")");
+        }
+    }
+    ~RcclGroup() {
+        if (open) (void)nc.GroupEnd();
+    }
+};
 
 // The output result of a concatenation / gather: per column a values buffer for `total` rows and, if any part carries a
 // validity bitmap, a validity bitmap (parts without one contribute ones).
@@ -353,7 +404,14 @@ int32_t qe_result_order_by(qe_ctx *ctx, const qe_result *src, int32_t column, qe
 }
 
 // Materialise a sharded result on rank `root`: *out is the concatenation in rank order there, NULL elsewhere.
-// Collective: every rank of the communicator calls it with its local result (same plan => same column types).
+// Collective: every rank of the communicator calls it with its local result (same plan => same column types; STRING
+// columns must hold the same dictionary on every rank -- codes travel, not strings).
+//
+// Shape of the call, chosen so that NO rank can be left waiting inside RCCL for a peer that has already given up:
+//   (1) all-gather of the result headers; every rank checks the SAME headers and so reaches the same verdict;
+//   (2) every rank allocates all it needs (the root: the output and the bitmap staging; a peer: its all-ones validity
+//       words) and the ranks all-gather one status word -- an allocation failure anywhere aborts the call everywhere;
+//   (3) only then ONE ncclGroupStart/End of the transfers, with nothing that can throw in between except RCCL itself.
 int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out) {
     if (!ctx || !local || !out) return QE_ERR_INVALID_ARG;
     *out = nullptr;
@@ -362,11 +420,14 @@ int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result *
         if (!ctx->comm) fail(QE_ERR_COMM, "qe_gather: no communicator (qe_comm_init)");
         const int nranks = ctx->comm_nranks, rank = ctx->comm_rank;
         if (root < 0 || root >= nranks) fail(QE_ERR_INVALID_ARG, "qe_gather: root out of range");
-        if (local->cols.size() > 16) fail(QE_ERR_UNSUPPORTED, "qe_gather: more than 16 columns");
+        // a rank whose local result cannot travel still takes part in the header exchange (with ncols = -1), so that the
+        // others do not wait for it
+        const bool too_wide = local->cols.size() > (size_t)kGatherMaxCols;
         RcclApi &nc = rccl();
         Scratch sc{ctx, {}};
-        // (1) all-gather of the result headers (32 B per rank): counts -> offsets, shapes are checked on every rank
-        const GatherHeader mine = header_of(local);
+        // (1) all-gather of the result headers: counts -> offsets; shapes and dictionaries are checked on every rank
+        GatherHeader mine = header_of(local, true);
+        if (too_wide) mine.ncols = -1;
         std::vector<GatherHeader> hdr((size_t)nranks);
         {
             GatherHeader *d_mine = (GatherHeader *)sc.get(sizeof(GatherHeader));
@@ -379,60 +440,107 @@ int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result *
         int64_t total = 0;
         uint32_t any_validity = 0;
         std::vector<int64_t> offset((size_t)nranks, 0);
+        const GatherHeader &ref = hdr[(size_t)root];    // every rank compares against the root's shape: one verdict everywhere
         for (int r = 0; r < nranks; r++) {
-            if (hdr[r].ncols != mine.ncols || hdr[r].type_sig != mine.type_sig)
-                fail(QE_ERR_INVALID_ARG, "qe_gather: rank " + std::to_string(r) + " holds a result of a different schema");
+            if (hdr[r].ncols < 0) fail(QE_ERR_UNSUPPORTED, "qe_gather: rank " + std::to_string(r) + " holds more than 16 columns");
+            if (hdr[r].ncols != ref.ncols || hdr[r].type_sig != ref.type_sig)
+                fail(QE_ERR_INVALID_ARG, "qe_gather: rank " + std::to_string(r) + " holds a result of a different schema than rank " +
+                                             std::to_string(root));
+            for (int c = 0; c < ref.ncols; c++)
+                if (hdr[r].dict_fp[c] != ref.dict_fp[c])
+                    fail(QE_ERR_INVALID_ARG, "qe_gather: column " + std::to_string(c) + " of rank " + std::to_string(r) +
+                                                 " has another dictionary than on rank " + std::to_string(root) +
+                                                 " (STRING columns travel as codes: every rank must pin the same dictionary)");
             offset[r] = total;
             total += hdr[r].count;
             any_validity |= hdr[r].validity_mask;
         }
         const size_t ncols = local->cols.size();
         const int64_t n_me = mine.count;
-        if (rank != root) {
-            // (2, peer) one grouped send per column buffer: values, then validity words (ones if this shard has none)
+
+        // (2) local allocations, then one status word per rank
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(nullptr, [ctx](qe_result *r) { free_output(ctx, r); });
+        std::vector<const uint64_t *> vsend(ncols, nullptr);   // what this rank contributes as validity words per column
+        struct Staged { uint64_t *words; int64_t off, n; uint64_t *dst; };
+        std::vector<Staged> staged;                            // root: received bitmap words waiting for their placement
+        int32_t my_status = QE_OK;
+        std::string my_error;
+        try {
             if (n_me > 0) {
-                std::vector<const uint64_t *> vsend(ncols, nullptr);
-                for (size_t c = 0; c < ncols; c++)
-                    if ((any_validity >> c) & 1u) vsend[c] = local->cols[c].validity ? local->cols[c].validity : ones_bitmap(ctx, sc, n_me);
-                QE_NCCL(nc.GroupStart());
+                const uint64_t *ones = nullptr;
+                for (size_t c = 0; c < ncols; c++) {
+                    if (!((any_validity >> c) & 1u)) continue;
+                    if (local->cols[c].validity) vsend[c] = local->cols[c].validity;
+                    else vsend[c] = ones ? ones : (ones = ones_bitmap(ctx, sc, n_me));
+                }
+            }
+            if (rank == root) {
+                res.reset(make_output(ctx, local, total, any_validity));
+                for (int r = 0; r < nranks; r++) {
+                    const int64_t n = hdr[r].count;
+                    if (n == 0 || r == root) continue;
+                    for (size_t c = 0; c < ncols; c++) {
+                        OutColumn &dst = res->cols[c];
+                        if (dst.type == QE_BOOLEAN) staged.push_back({(uint64_t *)sc.get(words_of(n) * 8), offset[r], n, (uint64_t *)dst.data});
+                        if (dst.nullable) staged.push_back({(uint64_t *)sc.get(words_of(n) * 8), offset[r], n, dst.validity});
+                    }
+                }
+            }
+        } catch (const Error &e) {
+            my_status = e.code;
+            my_error = e.msg;
+        } catch (const std::bad_alloc &) {
+            my_status = QE_ERR_OOM;
+            my_error = "host out of memory";
+        }
+        {
+            std::vector<int32_t> status((size_t)nranks, 0);
+            int32_t *d_mine = (int32_t *)sc.get(sizeof(int32_t));
+            int32_t *d_all = (int32_t *)sc.get(sizeof(int32_t) * (size_t)nranks);
+            QE_HIP(hipMemcpyAsync(d_mine, &my_status, sizeof my_status, hipMemcpyHostToDevice, ctx->stream));
+            QE_NCCL(nc.AllGather(d_mine, d_all, sizeof(int32_t), kNcclUint8, ctx->comm, ctx->stream));
+            QE_HIP(hipMemcpyAsync(status.data(), d_all, sizeof(int32_t) * (size_t)nranks, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            if (my_status != QE_OK) fail(my_status, "qe_gather: " + my_error);
+            for (int r = 0; r < nranks; r++)
+                if (status[r] != QE_OK)
+                    fail(status[r], "qe_gather: rank " + std::to_string(r) + " could not allocate its buffers; the exchange was not started");
+        }
+
+        // (3) the transfers.  Peer: one send per column buffer -- values, then validity words.  Root: values land at their
+        // final offset, bitmap words in the staging areas allocated above (same order as the peer's sends).
+        if (rank != root) {
+            if (n_me > 0) {
+                RcclGroup group(nc);
                 for (size_t c = 0; c < ncols; c++) {
                     const OutColumn &src = local->cols[c];
                     const size_t nb = src.type == QE_BOOLEAN ? words_of(n_me) * 8 : width_of(src.type) * (size_t)n_me;
                     QE_NCCL(nc.Send(src.data, nb, kNcclUint8, root, ctx->comm, ctx->stream));
                     if (vsend[c]) QE_NCCL(nc.Send(vsend[c], words_of(n_me) * 8, kNcclUint8, root, ctx->comm, ctx->stream));
                 }
-                QE_NCCL(nc.GroupEnd());
+                group.end();
             }
             QE_HIP(hipStreamSynchronize(ctx->stream));   // the local result (and the scratch) may be freed by the caller now
             return;
         }
-        // (2, root) receive every peer's values at their final offset; bitmap words into a staging area per (peer, column)
-        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(make_output(ctx, local, total, any_validity),
-                                                                          [ctx](qe_result *r) { free_output(ctx, r); });
-        struct Staged { uint64_t *words; int64_t off, n; uint64_t *dst; };
-        std::vector<Staged> staged;
-        QE_NCCL(nc.GroupStart());
-        for (int r = 0; r < nranks; r++) {
-            const int64_t n = hdr[r].count;
-            if (n == 0 || r == root) continue;
-            for (size_t c = 0; c < ncols; c++) {
-                OutColumn &dst = res->cols[c];
-                if (dst.type == QE_BOOLEAN) {
-                    uint64_t *st = (uint64_t *)sc.get(words_of(n) * 8);
-                    QE_NCCL(nc.Recv(st, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
-                    staged.push_back({st, offset[r], n, (uint64_t *)dst.data});
-                } else {
-                    QE_NCCL(nc.Recv((char *)dst.data + width_of(dst.type) * (size_t)offset[r], width_of(dst.type) * (size_t)n, kNcclUint8, r,
-                                    ctx->comm, ctx->stream));
-                }
-                if (dst.nullable) {
-                    uint64_t *st = (uint64_t *)sc.get(words_of(n) * 8);
-                    QE_NCCL(nc.Recv(st, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
-                    staged.push_back({st, offset[r], n, dst.validity});
+        {
+            RcclGroup group(nc);
+            size_t si = 0;
+            for (int r = 0; r < nranks; r++) {
+                const int64_t n = hdr[r].count;
+                if (n == 0 || r == root) continue;
+                for (size_t c = 0; c < ncols; c++) {
+                    OutColumn &dst = res->cols[c];
+                    if (dst.type == QE_BOOLEAN)
+                        QE_NCCL(nc.Recv(staged[si++].words, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
+                    else
+                        QE_NCCL(nc.Recv((char *)dst.data + width_of(dst.type) * (size_t)offset[r], width_of(dst.type) * (size_t)n, kNcclUint8, r,
+                                        ctx->comm, ctx->stream));
+                    if (dst.nullable) QE_NCCL(nc.Recv(staged[si++].words, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->stream));
                 }
             }
+            group.end();
         }
-        QE_NCCL(nc.GroupEnd());
         // the root's own shard: device-to-device, same placement code as the peers' segments
         if (n_me > 0) {
             for (size_t c = 0; c < ncols; c++) {
@@ -443,11 +551,10 @@ int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result *
                 else
                     QE_HIP(hipMemcpyAsync((char *)dst.data + width_of(src.type) * (size_t)offset[root], src.data,
                                           width_of(src.type) * (size_t)n_me, hipMemcpyDeviceToDevice, ctx->stream));
-                if (dst.nullable)
-                    launch_bitmap_place(ctx->stream, dst.validity, offset[root], src.validity ? src.validity : ones_bitmap(ctx, sc, n_me), n_me);
+                if (dst.nullable) launch_bitmap_place(ctx->stream, dst.validity, offset[root], vsend[c], n_me);
             }
         }
-        for (const Staged &s : staged) launch_bitmap_place(ctx->stream, s.dst, s.off, s.words, s.n);
+        for (const Staged &s_ : staged) launch_bitmap_place(ctx->stream, s_.dst, s_.off, s_.words, s_.n);
         QE_HIP(hipGetLastError());
         QE_HIP(hipStreamSynchronize(ctx->stream));
         *out = res.release();

@@ -42,3 +42,17 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "qe_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_product_does_not_reference_the_test_transport():
+    """tests/transport (the stand-in for librccl of the multi-rank exchange tests) is test infrastructure: the product
+    only knows the QE_RCCL_LIBRARY variable."""
+    pkg = os.path.join(ROOT, "queryengine_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "qe_test_transport" not in text and "tests/transport" not in text, f
+    for f in ("bench.py", "__graft_entry__.py"):
+        text = open(os.path.join(ROOT, f)).read()
+        assert "qe_test_transport" not in text and "tests/transport" not in text, f

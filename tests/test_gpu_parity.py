@@ -328,6 +328,56 @@ def test_full_size_1b_rows_properties(gpu_ctx, oracle):
     gpu_ctx.trim()
 
 
+def test_cfg5_rank7_shard_properties(gpu_ctx, oracle):
+    """BASELINE configs[4] ("cfg 5": 10 B rows row-range sharded over 8 GPUs), the single-GPU half of it: RANK 7's shard --
+    1.25 B rows whose GLOBAL row ids start at 7 x 1.25 B = 8.75e9 > 2^33 -- through the very workload object bench.py runs at
+    N > 1 (W.config2: same generator specs, filter, projections) plus one appended global-row-id column.  Properties: the
+    projected global row ids are strictly increasing inside [row_begin, row_begin + n) (order kept, nothing duplicated, the
+    shard offset really applied), count == an independent aggregate COUNT, the expected selectivity, the device generator ==
+    the oracle's generator at those global ids, two far-apart windows walked row by row by the oracle, a second run identical."""
+    from queryengine_amd import workloads as W
+    from queryengine_amd.distributed import shard_range
+    total, world, rank = 10_000_000_000, 8, 7
+    begin, end = shard_range(total, rank, world)
+    n = end - begin
+    assert n == 1_250_000_000 and begin == 8_750_000_000 and begin > 1 << 33
+    wl = W.config2(n)
+    specs = [c.spec(gpu_ctx) for c in wl.columns]
+    rid_spec = N.GenSpec(); rid_spec.kind = N.GEN_I64_ROWID; rid_spec.col_id = 99
+    batch = E.DeviceBatch.generate(gpu_ctx, specs + [rid_spec], n, row_begin=begin)
+    R_ = col("rowid", len(wl.columns), I64)
+    proj_exprs = list(wl.projections) + [R_]
+    cf = gpu_ctx.compile(wl.filter)
+    cp = [gpu_ctx.compile(p) for p in proj_exprs]
+    r1 = E.filter_project(gpu_ctx, batch, cf, cp)
+    cols1 = r1.to_columns()
+    rid = cols1[-1].data
+    assert abs(r1.count / n - 0.05) < 0.0005
+    assert np.all(np.diff(rid) > 0) and rid[0] >= begin and rid[-1] < end
+    vals, nsel = E.filter_aggregate(gpu_ctx, batch, cf, [gpu_ctx.compile(R_)], [N.AGG_COUNT])
+    assert nsel == r1.count == int(vals[0])
+    for local in (0, (n - 700_000) - (n - 700_000) % 64):
+        m = 600_000
+        win = [batch.column_to_host(j, local, m) for j in range(len(specs) + 1)]
+        assert win[-1].data[0] == begin + local and win[-1].data[-1] == begin + local + m - 1
+        for j, c in enumerate(wl.columns):      # the device generator at global ids > 2^33 == the oracle's
+            o = oracle.GenSpec(); o.kind, o.col_id, o.modulus, o.offset, o.step = c.kind, c.col_id, c.modulus, c.offset, c.step
+            o.aux_col_id, o.null_pct = c.aux_col_id, c.null_pct
+            data, _ = oracle.generate(o, 42, begin + local, m, np.float64 if c.type == D else np.int64)
+            assert np.array_equal(win[j].data.view(np.uint64), data.view(np.uint64)), f"generator, column {c.name}"
+        want = oracle.filter_project(win, wl.filter, proj_exprs, oracle.BYTECODE_COMPILER)
+        lo = int(np.searchsorted(rid, begin + local))
+        k = len(want[0])
+        assert k > 0 and np.array_equal(rid[lo:lo + k], want[-1].data)
+        assert lo + k == len(rid) or rid[lo + k] >= begin + local + m
+        for g, w in zip(cols1[:-1], want[:-1]):
+            assert_columns_equal(Column(g.type, g.data[lo:lo + k], None), w, f"cfg 5 rank 7 window at {local}")
+    r2 = E.filter_project(gpu_ctx, batch, cf, cp)
+    assert r2.count == r1.count and np.array_equal(r2.column_to_host(len(cp) - 1).data, rid)
+    r1.free(); r2.free(); batch.free()
+    gpu_ctx.trim()
+
+
 @pytest.mark.parametrize("name", ["config3", "config4", "config4_10keys"])
 def test_full_size_bench_workloads_properties(gpu_ctx, oracle, name):
     """BASELINE configs 3 and 4 at their FULL size, through the very workload objects bench.py runs (W.config3() /
