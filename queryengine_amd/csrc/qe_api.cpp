@@ -13,6 +13,7 @@
 #include "qe_internal.h"
 #include "qe_kernels.h"
 #include "qe_pernode.h"
+#include "qe_pernode_kernels.h"
 
 namespace qe {
 
@@ -499,6 +500,9 @@ namespace {
 // a plan that kept at least this share of its rows last time runs the dense single-pass kernel next time (measured
 // crossover against the LDS-ring kernel on cfg 2, 1 B rows: 10 % 4.14 vs 4.23 ms, 25 % 5.7 vs 4.5 ms)
 constexpr double kDenseFromSelectivity = 0.12;
+// a plan that kept at most this share of its rows last time runs the LOCAL form next time: scan without any inter-wave
+// dependency into per-chunk slots, then a scan over the counts and one move
+constexpr double kLocalUpToSelectivity = 0.03;
 constexpr int64_t kSampleFromRows = 8ll << 20;   // batches from here on sample their selectivity before the first execution of a plan
 constexpr int kScatterWgsPerCu = 2;   // workgroups per CU of the partitioned group-by's scatter pass
 
@@ -889,7 +893,87 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     const bool two_pass = !dense && plan->cg.has_filter && plan->cg.two_pass && !never_two_pass && n < (1ll << 32) &&
                           (force_two_pass || base->last_selectivity >= 0.6);   // measured crossover on cfg 2: 0.55 - 0.6
     unsigned long long total = 0;
-    if (dense) {
+    // LOCAL form (round 3): for plans that keep a few per cent of their rows at most.  The scan has no inter-wave dependency --
+    // no ticket, no descriptor, no look-back: every wave parks the kept rows of its (statically strided) chunks in per-chunk
+    // slots of ring_entries rows; a scan over the per-chunk counts and ONE move kernel put them at their final place.  The
+    // chunk is sized from the selectivity the plan showed so that it keeps ~ring_entries / 4 rows; a chunk that overflows its
+    // slot is reported by the kernel, this execution falls back to the single-pass kernel and the plan stays there.
+    const bool force_local = (ctx->opts.tuning[5] & 262144) != 0, never_local = (ctx->opts.tuning[5] & 524288) != 0;
+    const double local_upto = std::getenv("QE_LOCAL_UPTO") ? std::atof(std::getenv("QE_LOCAL_UPTO")) : kLocalUpToSelectivity;
+    bool local = plan->cg.has_filter && plan->cg.two_pass && !dense && !two_pass && !never_local && !base->local_overflowed &&
+                 (force_local || (n >= kSampleFromRows && base->last_selectivity >= 0 && base->last_selectivity <= local_upto));
+    if (local) {
+        const int64_t sub_rows = plan->geo.sub_rows(), ring = plan->geo.ring_entries;
+        const double sel = base->last_selectivity;
+        int64_t subs = sel > 0 ? (int64_t)((double)ring / (4.0 * sel) / (double)sub_rows) : 16;
+        if (sel < 0) subs = 1;                               // nothing known (forced): the smallest chunk
+        subs = std::max<int64_t>(1, std::min<int64_t>(subs, 16));
+        if (ctx->opts.tuning[4] % 10000 > 0) subs = ctx->opts.tuning[4] % 10000;   // explicit sub-tiles per chunk (measurement)
+        const int64_t crow = subs * sub_rows;
+        const int64_t nchunks = (n + crow - 1) / crow;
+        if (nchunks * ring >= (1ll << 32)) local = false;    // 32-bit offsets of the move
+        if (local) {
+            const int waves = plan->geo.threads / 64;
+            hipFunction_t f_scan = nullptr, f_move = nullptr;
+            QE_HIP(hipModuleGetFunction(&f_scan, plan->kernel.module, "qe_fl_scan"));
+            QE_HIP(hipModuleGetFunction(&f_move, plan->kernel.module, "qe_fl_move"));
+            std::vector<void *> scratch;
+            struct LocalGuard {
+                qe_ctx *c; std::vector<void *> &v;
+                ~LocalGuard() { for (void *q : v) c->pool.release(q); }
+            } lg{ctx, scratch};
+            const int64_t nsum = (nchunks + 1023) / 1024;
+            uint32_t *d_counts = (uint32_t *)ctx->pool.alloc((size_t)nchunks * 4);
+            scratch.push_back(d_counts);
+            uint32_t *d_offsets = (uint32_t *)ctx->pool.alloc((size_t)nchunks * 4);
+            scratch.push_back(d_offsets);
+            uint32_t *d_sums = (uint32_t *)ctx->pool.alloc((size_t)(nsum + 1) * 4);
+            scratch.push_back(d_sums);
+            FusedParams lp = p;
+            for (size_t i = 0; i < res->cols.size(); i++) {
+                const OutColumn &oc = res->cols[i];
+                const size_t w = oc.type == QE_BOOLEAN ? 1 : type_width(oc.type);
+                lp.stage[i] = ctx->pool.alloc((size_t)nchunks * (size_t)ring * w);
+                scratch.push_back(lp.stage[i]);
+                if (oc.nullable) {
+                    lp.stagevalid[i] = (unsigned char *)ctx->pool.alloc((size_t)nchunks * (size_t)ring);
+                    scratch.push_back(lp.stagevalid[i]);
+                }
+            }
+            lp.capacity = cap;
+            lp.nchunks = nchunks;
+            lp.stagger_rows = crow;
+            lp.blk = (unsigned long long *)d_counts;
+            lp.l1 = (unsigned long long *)d_offsets;
+            lp.error = ctx->d_ctrl + 1;
+            lp.total = (unsigned long long *)(ctx->d_ctrl + 2);
+            const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan);
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, max_grid));
+            const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)device_cus(ctx->device) * 8));
+            void *largs[] = {&lp};
+            QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 96, ctx->stream));
+            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+            QE_HIP(hipModuleLaunchKernel(f_scan, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, largs, nullptr));
+            pn::exclusive_scan_u32(ctx->stream, d_counts, d_offsets, d_sums, nchunks, lp.total);
+            QE_HIP(hipModuleLaunchKernel(f_move, mgrid, 1, 1, 256, 1, 1, 0, ctx->stream, largs, nullptr));
+            if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+            QE_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, 96, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            collect_time(ctx);
+            const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
+            if (hc[1] == 5) {            // some chunk kept more rows than its slot holds: this plan's rows are not spread evenly
+                local = false;
+                base->local_overflowed = true;
+            } else if (hc[1] != 0) {
+                fail(QE_ERR_INTERNAL, "local form: unexpected error flag");
+            } else {
+                total = ctx->h_ctrl[1];
+            }
+        }
+    }
+    if (local) {
+        // done above
+    } else if (dense) {
         auto dplan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, false, true);
         // a tile = the sub-tiles of one workgroup's waves; descriptors are per TILE
         const int waves = dplan->geo.threads / 64;
@@ -1071,7 +1155,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         if (hc[1] != 0) fail(QE_ERR_INTERNAL, "fused kernel: look-back spin limit reached (tile descriptor never published)");
         total = ctx->h_ctrl[1];
     }
-    ctx->last_form = !plan->cg.has_filter ? QE_FORM_NO_FILTER : dense ? QE_FORM_DENSE : two_pass ? QE_FORM_TWO_PASS : QE_FORM_RING;
+    ctx->last_form = !plan->cg.has_filter ? QE_FORM_NO_FILTER : local ? QE_FORM_LOCAL : dense ? QE_FORM_DENSE : two_pass ? QE_FORM_TWO_PASS : QE_FORM_RING;
     plan->last_selectivity = base->last_selectivity = (double)total / (double)n;
     if ((int64_t)total > cap)
         fail(QE_ERR_INVALID_ARG, "result has " + std::to_string(total) + " rows but result_capacity_rows is " +

@@ -265,6 +265,7 @@ struct Plan {
     mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
     mutable int64_t id_capacity = 0;          // .. of the key -> dense id table (qe_ht_build)
     mutable bool use_ids = false;             // .. the keys did not fit the LDS table last time: resolve them to dense ids first
+    mutable bool local_overflowed = false;    // filter+project: a chunk of the local form kept more rows than its slot holds: never again
     int est_regs = 0;                         // register estimate of the plan's geometry (get_plan)
     bool explicit_geometry = false;           // unroll / chunk / ring were fixed through qe_options.tuning
 };

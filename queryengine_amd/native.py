@@ -27,7 +27,7 @@ CMP_TOTAL_ORDER, CMP_IEEE = 0, 1
 GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE, GEN_DICT_MOD, GEN_I64_ROWID = range(8)
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_COUNT, AGG_AVG = range(5)
 COMM_ID_BYTES = 128
-FORM_RING, FORM_TWO_PASS, FORM_DENSE, FORM_PER_NODE, FORM_NO_FILTER = range(5)
+FORM_RING, FORM_TWO_PASS, FORM_DENSE, FORM_PER_NODE, FORM_NO_FILTER, FORM_LOCAL = range(6)
 
 
 class QeError(RuntimeError):

@@ -58,17 +58,29 @@ def gpu_ctx_two_pass(native_lib):
 
 @pytest.fixture(scope="session")
 def gpu_ctx_dense(native_lib):
-    """Fused executor forced into its dense single-pass form (chunk == sub-tile, blocking look-back, direct ordered stores
-    from the registers) -- normally chosen once a plan has kept >= 25 % of its rows (debug bit 16384 of tuning[5])."""
+    """Fused executor forced into its dense single-pass form (workgroup tiles, the kept rows of a tile parked in LDS and
+    resolved one tile later) -- normally chosen once a plan has kept >= 12 % of its rows (debug bit 16384 of tuning[5])."""
     from queryengine_amd import engine
     ctx = engine.Context(device=0, tuning=[0, 0, 0, 0, 0, 16384, 0, 0])
     yield ctx
     ctx.close()
 
 
-@pytest.fixture(params=["fused", "per_node", "fused_two_pass", "fused_dense"])
-def any_ctx(request, gpu_ctx, gpu_ctx_per_node, gpu_ctx_two_pass, gpu_ctx_dense):
+@pytest.fixture(scope="session")
+def gpu_ctx_local(native_lib):
+    """Fused executor forced into its local form (dependency-free scan into per-chunk slots, then a scan over the counts and
+    one move) -- normally chosen on large batches once a plan has kept <= 3 % of its rows (debug bit 262144 of tuning[5]).
+    A chunk that keeps more rows than its slot holds makes the execution fall back to the single-pass kernel: the parity
+    suite's high-selectivity cases run through exactly that fallback."""
+    from queryengine_amd import engine
+    ctx = engine.Context(device=0, tuning=[0, 0, 0, 0, 0, 262144, 0, 0])
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(params=["fused", "per_node", "fused_two_pass", "fused_dense", "fused_local"])
+def any_ctx(request, gpu_ctx, gpu_ctx_per_node, gpu_ctx_two_pass, gpu_ctx_dense, gpu_ctx_local):
     """Every parity test runs through ALL execution forms, like the reference's
     @EnumSource(Mode::class) tests run through all three evaluators (CompilerTest.kt:13)."""
     return {"fused": gpu_ctx, "per_node": gpu_ctx_per_node, "fused_two_pass": gpu_ctx_two_pass,
-            "fused_dense": gpu_ctx_dense}[request.param]
+            "fused_dense": gpu_ctx_dense, "fused_local": gpu_ctx_local}[request.param]

@@ -447,12 +447,14 @@ def test_dense_form_is_chosen_after_a_high_selectivity_run(oracle):
 def test_first_execution_samples_its_selectivity_on_a_large_batch(oracle):
     """From 8 Mi rows on, the FIRST execution of a plan estimates its selectivity from 256 chunks spread over the batch (the
     count pass of the two-pass form with a chunk stride) and starts in the form that fits: dense when the plan keeps >= 12 %
-    of its rows, the LDS ring otherwise.  Same rows either way: two windows are walked by the oracle, the count must equal
+    of its rows, the local form (dependency-free scan into per-chunk slots + one move) when it keeps <= 3 %, the LDS ring in
+    between.  Same rows either way: two windows are walked by the oracle, the count must equal
     the next execution's, and debug bit 65536 switches the sample off (first execution = ring)."""
     from queryengine_amd import engine as E
     from queryengine_amd import workloads as W
     n = 12_000_017
     for a_limit, c_limit, want_form, tuning in ((1000, 1.0, N.FORM_DENSE, []), (400, 0.5, N.FORM_DENSE, []), (100, 0.5, N.FORM_RING, []),
+                                                (20, 0.5, N.FORM_LOCAL, []), (20, 0.5, N.FORM_RING, [0, 0, 0, 0, 0, 524288]),
                                                 (1000, 1.0, N.FORM_RING, [0, 0, 0, 0, 0, 65536])):
         ctx = E.Context(device=0, tuning=tuning)
         wl = W.config2(n, a_limit=a_limit, c_limit=c_limit)
@@ -476,6 +478,45 @@ def test_first_execution_samples_its_selectivity_on_a_large_batch(oracle):
             assert_columns_equal(Column(g.type, g.data[:k], None, g.dictionary), w, f"a<{a_limit} c<{c_limit}: head window")
         batch.free()
         ctx.close()
+
+
+def test_local_form_falls_back_when_a_chunk_overflows_its_slot(oracle):
+    """The local form parks a chunk's kept rows in a slot of ring_entries rows.  Kept rows that are CLUSTERED (here: one
+    dense stretch in an otherwise empty batch -- 1.5 % overall, so the sample picks the local form) overflow the slots of
+    the chunks they fall in: the kernel reports it, the SAME execution answers through the single-pass kernel (same rows,
+    same order) and the plan does not try the local form again."""
+    from queryengine_amd import engine as E
+    n = 9_000_001
+    a = np.full(n, 500, dtype=np.int64)
+    lo, hi = 3_000_000, 3_135_000
+    a[lo:hi] = 7
+    rid = np.arange(n, dtype=np.int64)
+    cols = [Column(I64, a, None), Column(I64, rid, None)]
+    A_, R_ = col("a", 0, I64), col("rid", 1, I64)
+    flt = fn(Fn.CMP_LT, A_, num(100))
+    ctx = E.Context(device=0)
+    batch = E.DeviceBatch.from_columns(ctx, cols)
+    cf, cp = ctx.compile(flt), [ctx.compile(R_), ctx.compile(fn(Fn.ADD, A_, R_))]
+    for rep in range(3):
+        res = E.filter_project(ctx, batch, cf, cp)
+        assert ctx.last_form == N.FORM_RING, (rep, ctx.last_form)     # rep 0: local tried, overflowed, fell back; later: not tried
+        got = res.to_columns()
+        res.free()
+        assert len(got[0]) == hi - lo
+        assert np.array_equal(got[0].data, rid[lo:hi]) and np.array_equal(got[1].data, rid[lo:hi] + 7)
+    # the same data spread evenly keeps the local form
+    a2 = np.where(rid % 67 == 0, 7, 500).astype(np.int64)
+    b2 = E.DeviceBatch.from_columns(ctx, [Column(I64, a2, None), Column(I64, rid, None)])
+    flt2 = fn(Fn.CMP_LT, A_, num(99))      # another plan (another literal): its own memory
+    cf2 = ctx.compile(flt2)
+    for rep in range(2):
+        res = E.filter_project(ctx, b2, cf2, cp)
+        assert ctx.last_form == N.FORM_LOCAL
+        got = res.to_columns()
+        res.free()
+        assert np.array_equal(got[0].data, rid[rid % 67 == 0]) and np.array_equal(got[1].data, rid[rid % 67 == 0] + 7)
+    batch.free(); b2.free()
+    ctx.close()
 
 
 @pytest.mark.parametrize("seed", range(8 + int(os.environ.get("QE_FUZZ_EXTRA", "0"))))
