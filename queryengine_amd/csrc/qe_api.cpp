@@ -903,11 +903,14 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     bool local = plan->cg.has_filter && plan->cg.two_pass && !dense && !two_pass && !never_local && !base->local_overflowed &&
                  (force_local || (n >= kSampleFromRows && base->last_selectivity >= 0 && base->last_selectivity <= local_upto));
     if (local) {
-        const int64_t sub_rows = plan->geo.sub_rows(), ring = plan->geo.ring_entries;
+        const int64_t sub_rows = plan->geo.sub_rows(), ring = plan->cg.fl_ring;
         const double sel = base->last_selectivity;
-        int64_t subs = sel > 0 ? (int64_t)((double)ring / (4.0 * sel) / (double)sub_rows) : 16;
+        // expected kept rows per chunk = slot / fill: 2.5 leaves 1.5 slots of head room over the mean (a binomial count of ~200
+        // has a standard deviation of ~14); larger chunks were measured faster (cfg 3: 2 Ki rows 2.07 ms, 8 Ki rows 1.71 ms)
+        static const double fill = std::getenv("QE_LOCAL_FILL") ? std::atof(std::getenv("QE_LOCAL_FILL")) : 2.5;
+        int64_t subs = sel > 0 ? (int64_t)((double)ring / (fill * sel) / (double)sub_rows) : 32;
         if (sel < 0) subs = 1;                               // nothing known (forced): the smallest chunk
-        subs = std::max<int64_t>(1, std::min<int64_t>(subs, 16));
+        subs = std::max<int64_t>(1, std::min<int64_t>(subs, 32));
         if (ctx->opts.tuning[4] % 10000 > 0) subs = ctx->opts.tuning[4] % 10000;   // explicit sub-tiles per chunk (measurement)
         const int64_t crow = subs * sub_rows;
         const int64_t nchunks = (n + crow - 1) / crow;
@@ -947,7 +950,10 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             lp.l1 = (unsigned long long *)d_offsets;
             lp.error = ctx->d_ctrl + 1;
             lp.total = (unsigned long long *)(ctx->d_ctrl + 2);
-            const int64_t max_grid = (int64_t)device_cus(ctx->device) * blocks_per_cu(ctx, *plan);
+            // 20 waves per CU: measured on cfg 3 (600 M rows) 12 / 16 / 20 / 24 waves per CU = 1.99 / 1.85 / 1.78 / 1.85 ms, on cfg 4
+            // 0.665 / 0.654 / 0.661 / 0.670 ms -- past 20 the extra streams cost more than the extra loads in flight bring
+            const int bpc = ctx->opts.tuning[3] % 100 > 0 ? blocks_per_cu(ctx, *plan) : std::min(blocks_per_cu(ctx, *plan), std::max(1, 20 / waves));
+            const int64_t max_grid = (int64_t)device_cus(ctx->device) * bpc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, max_grid));
             const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)device_cus(ctx->device) * 8));
             void *largs[] = {&lp};

@@ -203,6 +203,7 @@ struct CodegenOutput {
     bool has_filter = false;
     bool two_pass = false;       // the module also holds qe_fp_count / qe_fp_write (count + direct ordered write)
     bool dense = false;          // the module holds the dense single-pass kernel only (entry qe_fused)
+    int fl_ring = 0;             // local form (qe_fl_scan / qe_fl_move): rows per chunk slot = LDS entries per wave
     std::vector<std::vector<int32_t>> aux_tables;   // int32 tables indexed by dictionary codes (string ranks, remaps): col[kMaxCols-1-k]
     // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
     // accumulator table geometry: ngroups rows of table_words u64 words {first row, (count, acc) per aggregate}
