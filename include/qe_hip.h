@@ -264,10 +264,28 @@ typedef struct {
 int64_t qe_result_count(const qe_result *result);
 int32_t qe_result_ncols(const qe_result *result);
 int32_t qe_result_column(const qe_result *result, int32_t col, qe_col_view *out);
-/* copy one output column to host buffers sized for qe_result_count rows */
+/* copy one output column to the CALLER's host buffers sized for qe_result_count rows (pageable memory is fine: the bytes
+ * are staged through pinned chunks and copied out by a few host threads while the next chunk is on the link) */
 int32_t qe_result_column_to_host(qe_ctx *ctx, const qe_result *result, int32_t col, void *data_out,
                                  uint64_t *validity_out);
 void qe_result_free(qe_ctx *ctx, qe_result *result);
+
+/* Result -> host, the way a caller that materialises rows wants it (Main.kt:18 `physicalPlan.map { it }`;
+ * operator/Operators.kt:5-11 hands out host rows): every column is copied into PINNED host memory owned by the library
+ * (pooled per context: a re-opened operator does not pin again) on the context's COPY stream.  qe_result_to_host only
+ * starts the copies and returns -- the next qe_filter_project (compute stream) runs beside them; qe_host_result_wait blocks
+ * until the bytes are there; qe_host_result_column then gives HOST pointers in the qe_col_view (same layouts as on the
+ * device; validity NULL = no NULL in the column); qe_host_result_free returns the buffers to the pool.  `result` must stay
+ * alive until the wait has returned (qe_result_free waits for a copy that still reads it).  Into pinned memory the link
+ * runs at its own rate (0.8 GB: ~15 ms) where a copy into pageable memory (qe_result_column_to_host) is bound by host
+ * memcpy; the kernel itself is not overlapped with the copy of ITS OWN result: it takes 3 ms, the copy 15. */
+typedef struct qe_host_result qe_host_result;
+int32_t qe_result_to_host(qe_ctx *ctx, const qe_result *result, qe_host_result **out);
+int32_t qe_host_result_wait(qe_ctx *ctx, qe_host_result *host);
+int64_t qe_host_result_count(const qe_host_result *host);
+int32_t qe_host_result_ncols(const qe_host_result *host);
+int32_t qe_host_result_column(const qe_host_result *host, int32_t col, qe_col_view *out);
+void qe_host_result_free(qe_ctx *ctx, qe_host_result *host);
 /* Concatenate results of ONE device, in the given order, into a new result (value columns at row offsets, bitmap
  * columns shifted into place as 64-row words): what a host does that feeds a table batch by batch and still hands the
  * reference's single Operator (operator/Operators.kt:5-11) the whole result.  Parts must share schema and dictionaries. */
@@ -317,6 +335,14 @@ int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_ex
 int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                    const qe_expr *const *projections, int32_t nproj, int32_t *out_chosen,
                                    int32_t *out_from_cache);
+/* The order in which this plan evaluates the conjuncts of its filter's top-level AND chain (and so loads their columns):
+ * out_order[k] = index, in WRITTEN order, of the conjunct evaluated k-th.  *out_nconj = number of conjuncts, or -1 while
+ * the plan has not measured yet (its first execution on a batch of >= 8 Mi rows measures every conjunct's pass rate and
+ * keeps the order that fetches the fewest lines; smaller batches run as written).  The reference's AND is lazy left to
+ * right (evaluator/Interpreter.kt:54-72) -- with typed plans and no side effects any order keeps the same rows. */
+int32_t qe_filter_project_conjunct_order(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                         const qe_expr *const *projections, int32_t nproj, int32_t *out_order, int32_t capacity,
+                                         int32_t *out_nconj);
 /* Which form the last qe_filter_project on this context ran in (-1: none yet).  The fused executor picks the form from the
  * share of rows the plan kept last time: the local form up to 3 % (large batches), the LDS-ring single pass below 12 %, the
  * dense single pass from there on. */

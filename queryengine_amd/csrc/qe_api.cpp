@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <functional>
 #include <sstream>
+#include <thread>
 
 #include "qe_internal.h"
 #include "qe_kernels.h"
@@ -75,6 +76,43 @@ void Pool::trim_all() {
     bytes_cached = 0;
 }
 void Pool::trim() { trim_all(); }
+
+void *PinnedPool::alloc(size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 64) + 4095) & ~(size_t)4095;
+    auto it = free_.lower_bound(bytes);
+    if (it != free_.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {   // a cached buffer that is not wastefully large
+        void *p = it->second;
+        live_[p] = it->first;
+        free_.erase(it);
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        trim();   // give the cached buffers back and try once more
+        e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail(QE_ERR_OOM, "hipHostMalloc of " + std::to_string(bytes) + " bytes of pinned host memory failed: " + hipGetErrorString(e));
+        }
+    }
+    live_[p] = bytes;
+    return p;
+}
+
+void PinnedPool::release(void *p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+
+void PinnedPool::trim() {
+    for (auto &kv : free_) (void)hipHostFree(kv.second);
+    free_.clear();
+}
 
 }  // namespace qe
 
@@ -165,6 +203,7 @@ int32_t qe_ctx_create(int32_t device, const qe_options *opts, qe_ctx **out) {
         ctx->opts.struct_size = sizeof(qe_options);
         QE_HIP(hipSetDevice(device));
         QE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        QE_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         QE_HIP(hipEventCreate(&ctx->ev0));
         QE_HIP(hipEventCreate(&ctx->ev1));
         QE_HIP(hipMalloc((void **)&ctx->d_ctrl, 256));
@@ -188,6 +227,9 @@ void qe_ctx_destroy(qe_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    while (!ctx->host_results.empty()) qe_host_result_free(ctx, ctx->host_results.back());
+    ctx->pinned.trim();
     qe_comm_destroy(ctx);
     ctx->plans.clear();
     ctx->jit.reset();
@@ -197,6 +239,7 @@ void qe_ctx_destroy(qe_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -234,6 +277,7 @@ int32_t qe_ctx_trim(qe_ctx *ctx) {
         need_device(ctx);
         QE_HIP(hipStreamSynchronize(ctx->stream));
         ctx->pool.trim();
+        ctx->pinned.trim();
     });
 }
 
@@ -534,7 +578,8 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
 
 std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load,
-                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false, bool dense = false) {
+                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false, bool dense = false,
+                               const std::vector<int> *conj_order = nullptr) {
     if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
     CodegenInput in;
     in.filter = filter ? &filter->e : nullptr;
@@ -551,6 +596,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         in.group_keys.push_back(&keys[i]->e);
     }
     in.cmp_semantics = ctx->opts.cmp_semantics;
+    if (conj_order) in.conj_order = *conj_order;
     in.geo = geometry_of(ctx);
     if (wide) {   // the second candidate of the geometry choice (qe_ctx::geo_choice)
         in.geo.unroll = 16;
@@ -592,6 +638,10 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     }
     if (agg_fns)
         for (int a : in.agg_fns) key << "|a" << a;
+    if (!in.conj_order.empty()) {
+        key << "|O";
+        for (int o : in.conj_order) key << o << ".";
+    }
     const std::string k = key.str();
     auto it = ctx->plans.find(k);
     if (it != ctx->plans.end() && (it->second->kernel.fn || !load)) return it->second;
@@ -789,6 +839,61 @@ void free_result(qe_ctx *ctx, qe_result *r) {
     delete r;
 }
 
+// Pass rate of every conjunct on its own (qe_conj_probe), then the evaluation order that fetches the fewest 128-byte lines.
+// Model: a column of w bytes per row, needed where a share d of the rows is still alive, costs w * (1 - (1 - d)^(128 / w)) bytes
+// per row (whole lines are fetched); conjuncts are taken as independent; the projections' columns are read at the final
+// density whatever the order.  Up to 6 conjuncts: every permutation; more: as written.  Returns {} for "as written".
+std::vector<int> choose_conjunct_order(qe_ctx *ctx, const qe_batch *batch, const Plan &plan) {
+    const int K = plan.cg.nconj;
+    if (K < 2 || K > 6 || (int)plan.cg.conj_cols.size() != K) return {};
+    const int64_t n = batch->nrows, sub_rows = plan.geo.sub_rows();
+    const int64_t full_subs = n / sub_rows;
+    const int64_t S = std::min<int64_t>(256, full_subs);
+    if (S < 16) return {};
+    hipFunction_t f_probe = nullptr;
+    QE_HIP(hipModuleGetFunction(&f_probe, plan.kernel.module, "qe_conj_probe"));
+    uint32_t *d_cnt = (uint32_t *)ctx->pool.alloc(64 * 4);
+    struct G { qe_ctx *c; void *q; ~G() { c->pool.release(q); } } g{ctx, d_cnt};
+    FusedParams pp;
+    fill_inputs(pp, batch, plan);
+    pp.nchunks = S;
+    pp.stagger_rows = (full_subs / S) * sub_rows;
+    pp.blk = (unsigned long long *)d_cnt;
+    void *args[] = {&pp};
+    const int waves = plan.geo.threads / 64;
+    QE_HIP(hipMemsetAsync(d_cnt, 0, 64 * 4, ctx->stream));
+    QE_HIP(hipModuleLaunchKernel(f_probe, (unsigned)((S + waves - 1) / waves), 1, 1, plan.geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+    uint32_t h[64];
+    QE_HIP(hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<double> rate((size_t)K);
+    for (int i = 0; i < K; i++) rate[(size_t)i] = (double)h[i] / (double)(S * sub_rows);
+    auto lines = [](double d, int w) { return w <= 0 ? 0.0 : (double)w * (1.0 - std::pow(1.0 - std::min(1.0, std::max(0.0, d)), 128.0 / (double)w)); };
+    const size_t ncols = plan.cg.col_width.size();
+    auto cost_of = [&](const std::vector<int> &perm) {
+        std::vector<char> loaded(ncols, 0);
+        double alive = 1.0, cost = 0.0;
+        for (int k : perm) {
+            for (int c : plan.cg.conj_cols[(size_t)k])
+                if (!loaded[(size_t)c]) { loaded[(size_t)c] = 1; cost += lines(alive, plan.cg.col_width[(size_t)c]); }
+            alive *= rate[(size_t)k];
+        }
+        return cost;   // (+ the projection-only columns at the final density: the same for every order)
+    };
+    std::vector<int> perm((size_t)K), best;
+    for (int i = 0; i < K; i++) perm[(size_t)i] = i;
+    const std::vector<int> identity = perm;
+    const double written = cost_of(identity);
+    double best_cost = written;
+    do {
+        const double c = cost_of(perm);
+        if (c < best_cost - 1e-9) { best_cost = c; best = perm; }
+    } while (std::next_permutation(perm.begin(), perm.end()));
+    // a different order must save at least 3 % of the filter's bytes: otherwise the written order stays (one kernel fewer to build)
+    if (best.empty() || best_cost > 0.97 * written) return {};
+    return best;
+}
+
 qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projs,
                      int32_t nproj) {
     auto plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true);
@@ -797,6 +902,18 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
     // shape (cfg 2: the wide one by 5-8 %; cfg 3: the default by 25 %), so on a large batch the first two executions of a
     // plan time one each and the faster one is kept.  Same rows, same order either way.
     const std::shared_ptr<Plan> base = plan;
+    // Conjunct order (round 3): the load stages follow the evaluation order of the filter's AND chain.  As written,
+    // `c < 0.5 AND a < 100` reads c in full and a for half of the rows; evaluated as `a < 100 AND c < 0.5` it reads a in full, c
+    // where a passes.  On its first execution on a large batch a plan measures the pass rate of every conjunct on its own
+    // (qe_conj_probe over 256 sub-tiles spread over the batch), the host picks the order that fetches the fewest 128-byte
+    // lines, and the plan keeps it.  Same rows, same order: a row is kept iff every conjunct is TRUE.
+    if (base->cg.has_probe && !base->conj_decided && n >= kSampleFromRows && (ctx->opts.tuning[5] & 1048576) == 0) {
+        base->conj_decided = true;
+        base->conj_order = choose_conjunct_order(ctx, batch, *base);
+    }
+    std::vector<int> order = base->conj_order;
+    if (!order.empty()) plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, false, false, &order);
+    const std::shared_ptr<Plan> obase = plan;   // the plan in the chosen order, default geometry: what the memories below hang on
     qe_ctx::GeoChoice *choice = nullptr;
     int cand = 0;
     {
@@ -804,17 +921,17 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         const bool eligible = !plan->explicit_geometry && plan->est_regs > 0 && n >= (32ll << 20) &&   // (a plain projection too: 6.5 vs 7.3 ms)
                               32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0;
         if (eligible) {
-            const bool fresh = ctx->geo_choice.find(base.get()) == ctx->geo_choice.end();
-            choice = &ctx->geo_choice[base.get()];
+            const bool fresh = ctx->geo_choice.find(obase.get()) == ctx->geo_choice.end();
+            choice = &ctx->geo_choice[obase.get()];
             if (fresh) {   // a decision measured earlier (another context / process) is kept: same plan => same geometry
-                const int saved = ctx->jit->load_choice(base->cg.source);
+                const int saved = ctx->jit->load_choice(obase->cg.source);
                 if (saved >= 0) { choice->chosen = saved; choice->from_cache = true; }
             }
             // exploring: the candidates alternate, kGeoRuns timed executions each, best time wins
             cand = choice->chosen >= 0 ? choice->chosen : (choice->runs[0] <= choice->runs[1] ? 0 : 1);
             if (cand == 1) {
                 try {
-                    plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true);
+                    plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true, false, order.empty() ? nullptr : &order);
                 } catch (const Error &) {   // the wide candidate does not build for this plan: the default stays
                     choice->chosen = 0;
                     cand = 0;
@@ -1143,7 +1260,7 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
                 char note[160];
                 std::snprintf(note, sizeof note, "default %.4f ms, wide %.4f ms (best of %d each, %lld rows)", choice->best_ms[0],
                               choice->best_ms[1], kGeoRuns, (long long)n);
-                ctx->jit->store_choice(base->cg.source, choice->chosen, note);
+                ctx->jit->store_choice(obase->cg.source, choice->chosen, note);
             }
         }
         if ((ctx->opts.tuning[5] & 32) && std::getenv("QE_TRACE_FILE")) {
@@ -1780,6 +1897,8 @@ int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_
     if (!ctx || !batch || !out_chosen) return QE_ERR_INVALID_ARG;
     return guarded(ctx, [&] {
         auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false);
+        if (!plan->conj_order.empty())   // the geometry memory belongs to the plan in its chosen conjunct order
+            plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false, nullptr, 0, false, false, &plan->conj_order);
         *out_chosen = -1;
         if (out_from_cache) *out_from_cache = 0;
         auto it = ctx->geo_choice.find(plan.get());
@@ -1793,6 +1912,18 @@ int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_
                 if (out_from_cache) *out_from_cache = 1;
             }
         }
+    });
+}
+
+int32_t qe_filter_project_conjunct_order(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
+                                         const qe_expr *const *projections, int32_t nproj, int32_t *out_order, int32_t capacity,
+                                         int32_t *out_nconj) {
+    if (!ctx || !batch || !out_nconj || capacity < 0 || (capacity > 0 && !out_order)) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        auto plan = get_plan(ctx, batch, filter, projections, nproj, nullptr, false);
+        const int K = plan->cg.nconj;
+        *out_nconj = plan->conj_decided ? K : -1;
+        for (int i = 0; i < K && i < capacity; i++) out_order[i] = plan->conj_order.empty() ? i : plan->conj_order[(size_t)i];
     });
 }
 
@@ -1908,26 +2039,165 @@ int32_t qe_result_column(const qe_result *r, int32_t col, qe_col_view *out) {
     return QE_OK;
 }
 
+// Device -> a caller's PAGEABLE buffer.  One hipMemcpy into pageable memory ran at 7 GB/s here (0.8 GB in 108 ms) while the
+// link does ~55 GB/s into pinned memory: the bytes go through two pinned staging chunks on the copy stream, and the chunk
+// that has arrived is copied into the caller's buffer (by a few host threads: one memcpy thread does ~10 GB/s) while the
+// next one is on the link.
+static void parallel_memcpy(void *dst, const void *src, size_t n) {
+    const size_t kMin = 4u << 20;
+    unsigned nthr = (unsigned)std::min<size_t>(4, n / kMin);
+    if (nthr <= 1) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> ts;
+    const size_t per = ((n / nthr) + 4095) & ~(size_t)4095;
+    for (unsigned t = 1; t < nthr; t++) {
+        const size_t off = (size_t)t * per;
+        if (off >= n) break;
+        const size_t len = std::min(per, n - off);
+        ts.emplace_back([=] { std::memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    std::memcpy(dst, src, std::min(per, n));
+    for (auto &t : ts) t.join();
+}
+
+static void staged_d2h(qe_ctx *ctx, void *dst, const void *src, size_t n) {
+    const size_t kChunk = 32u << 20;
+    if (n <= (1u << 20)) {   // small: not worth the staging
+        QE_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx->copy_stream));
+        QE_HIP(hipStreamSynchronize(ctx->copy_stream));
+        return;
+    }
+    void *stage[2] = {ctx->pinned.alloc(std::min(n, kChunk)), ctx->pinned.alloc(std::min(n, kChunk))};
+    struct G { qe_ctx *c; void **s; ~G() { c->pinned.release(s[0]); c->pinned.release(s[1]); } } g{ctx, stage};
+    hipEvent_t ev[2];
+    QE_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    QE_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    struct EG { hipEvent_t *e; ~EG() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } eg{ev};
+    const size_t nchunks = (n + kChunk - 1) / kChunk;
+    auto issue = [&](size_t k) {
+        const size_t off = k * kChunk, len = std::min(kChunk, n - off);
+        QE_HIP(hipMemcpyAsync(stage[k & 1], (const char *)src + off, len, hipMemcpyDeviceToHost, ctx->copy_stream));
+        QE_HIP(hipEventRecord(ev[k & 1], ctx->copy_stream));
+    };
+    issue(0);
+    for (size_t k = 0; k < nchunks; k++) {
+        if (k + 1 < nchunks) issue(k + 1);
+        QE_HIP(hipEventSynchronize(ev[k & 1]));
+        const size_t off = k * kChunk, len = std::min(kChunk, n - off);
+        parallel_memcpy((char *)dst + off, stage[k & 1], len);
+    }
+}
+
 int32_t qe_result_column_to_host(qe_ctx *ctx, const qe_result *r, int32_t col, void *data_out, uint64_t *validity_out) {
     if (!ctx || !r || col < 0 || col >= (int32_t)r->cols.size()) return QE_ERR_INVALID_ARG;
     return guarded(ctx, [&] {
         need_device(ctx);
         const OutColumn &c = r->cols[col];
         if (r->count == 0) return;
-        if (data_out)
-            QE_HIP(hipMemcpyAsync(data_out, c.data, column_bytes(c.type, r->count), hipMemcpyDeviceToHost, ctx->stream));
+        if (data_out) staged_d2h(ctx, data_out, c.data, column_bytes(c.type, r->count));
         if (validity_out) {
-            if (c.validity)
-                QE_HIP(hipMemcpyAsync(validity_out, c.validity, bitmap_bytes(r->count), hipMemcpyDeviceToHost, ctx->stream));
-            else
-                std::memset(validity_out, 0xff, bitmap_bytes(r->count));
+            if (c.validity) staged_d2h(ctx, validity_out, c.validity, bitmap_bytes(r->count));
+            else std::memset(validity_out, 0xff, bitmap_bytes(r->count));
         }
-        QE_HIP(hipStreamSynchronize(ctx->stream));
     });
+}
+
+// Result -> PINNED host memory owned by the library, on the context's copy stream: the call returns at once, so the scan of
+// the next batch (compute stream) runs beside the copy; qe_host_result_wait blocks until the bytes are there.  What a host
+// that materialises rows (Main.kt:18 `physicalPlan.map { it }`, Operators.kt:5-11) reads them from -- no second copy.
+int32_t qe_result_to_host(qe_ctx *ctx, const qe_result *r, qe_host_result **out) {
+    if (!ctx || !r || !out) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        need_device(ctx);
+        std::unique_ptr<qe_host_result> h(new qe_host_result());
+        h->count = r->count;
+        try {
+            for (const OutColumn &c : r->cols) {
+                qe_host_result::Col hc;
+                hc.type = c.type;
+                hc.nullable = c.validity != nullptr;
+                hc.dict = c.dict;
+                hc.dict_handle.d = c.dict;
+                h->cols.push_back(hc);
+                qe_host_result::Col &d = h->cols.back();
+                d.data = ctx->pinned.alloc(std::max<size_t>(column_bytes(c.type, r->count), 64));
+                if (c.validity) d.validity = (uint64_t *)ctx->pinned.alloc(std::max<size_t>(bitmap_bytes(r->count), 64));
+            }
+            QE_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
+            if (r->count > 0) {
+                for (size_t i = 0; i < r->cols.size(); i++) {
+                    const OutColumn &c = r->cols[i];
+                    QE_HIP(hipMemcpyAsync(h->cols[i].data, c.data, column_bytes(c.type, r->count), hipMemcpyDeviceToHost, ctx->copy_stream));
+                    if (c.validity)
+                        QE_HIP(hipMemcpyAsync(h->cols[i].validity, c.validity, bitmap_bytes(r->count), hipMemcpyDeviceToHost, ctx->copy_stream));
+                }
+            }
+            QE_HIP(hipEventRecord(h->done, ctx->copy_stream));
+        } catch (...) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            for (auto &c : h->cols) {
+                ctx->pinned.release(c.data);
+                ctx->pinned.release(c.validity);
+            }
+            if (h->done) (void)hipEventDestroy(h->done);
+            throw;
+        }
+        h->src = r;
+        ctx->host_results.push_back(h.get());
+        *out = h.release();
+    });
+}
+
+int32_t qe_host_result_wait(qe_ctx *ctx, qe_host_result *h) {
+    if (!ctx || !h) return QE_ERR_INVALID_ARG;
+    return guarded(ctx, [&] {
+        if (h->waited) return;
+        QE_HIP(hipEventSynchronize(h->done));
+        h->waited = true;
+        h->src = nullptr;
+    });
+}
+
+int64_t qe_host_result_count(const qe_host_result *h) { return h ? h->count : -1; }
+int32_t qe_host_result_ncols(const qe_host_result *h) { return h ? (int32_t)h->cols.size() : -1; }
+
+int32_t qe_host_result_column(const qe_host_result *h, int32_t col, qe_col_view *out) {
+    if (!h || !out || col < 0 || col >= (int32_t)h->cols.size()) return QE_ERR_INVALID_ARG;
+    const qe_host_result::Col &c = h->cols[col];
+    out->type = c.type;
+    out->nullable = c.nullable ? 1 : 0;
+    out->data = c.data;
+    out->validity = c.validity;
+    out->count = h->count;
+    out->dict = c.type == QE_STRING ? &c.dict_handle : nullptr;
+    return QE_OK;
+}
+
+void qe_host_result_free(qe_ctx *ctx, qe_host_result *h) {
+    if (!ctx || !h) return;
+    if (!h->waited && h->done) (void)hipEventSynchronize(h->done);   // the copies write into the buffers released below
+    for (auto &c : h->cols) {
+        ctx->pinned.release(c.data);
+        ctx->pinned.release(c.validity);
+    }
+    if (h->done) (void)hipEventDestroy(h->done);
+    auto &v = ctx->host_results;
+    v.erase(std::remove(v.begin(), v.end(), h), v.end());
+    delete h;
 }
 
 void qe_result_free(qe_ctx *ctx, qe_result *r) {
     if (!ctx) return;
+    // a copy to the host that still reads this result must finish before its buffers go back to the pool
+    for (qe_host_result *h : ctx->host_results)
+        if (h->src == r) {
+            if (h->done) (void)hipEventSynchronize(h->done);
+            h->waited = true;
+            h->src = nullptr;
+        }
     free_result(ctx, r);
 }
 

@@ -97,6 +97,20 @@ private:
     std::unordered_map<void *, size_t> live_;
 };
 
+// Pinned (page-locked) host buffers, recycled per context like the device pool: hipHostMalloc pins pages at ~1 GB/s-scale
+// rates, a re-opened operator must not pay that per open() (T/SimpleSumBenchmark.java:63-94 re-runs one plan).
+class PinnedPool {
+public:
+    void *alloc(size_t bytes);
+    void release(void *p);
+    void trim();
+    ~PinnedPool() { trim(); }
+
+private:
+    std::multimap<size_t, void *> free_;
+    std::unordered_map<void *, size_t> live_;
+};
+
 struct Column {
     int type = 0;
     void *data = nullptr;            // device
@@ -188,6 +202,7 @@ struct CodegenInput {
     FusedGeometry geo;
     int nontemporal = 1;
     int nt_stores = 1;    // non-temporal stores for the output rows
+    std::vector<int> conj_order;  // evaluation order of the filter's conjuncts (a permutation of their written order); empty = as written
     int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
     bool staged = true;   // late materialisation: evaluate the filter's AND chain conjunct by conjunct, load later columns for live rows only
     bool dense = false;   // filter+project only: generate the DENSE single-pass kernel (chunk == sub-tile, blocking look-back between
@@ -203,6 +218,10 @@ struct CodegenOutput {
     bool has_filter = false;
     bool two_pass = false;       // the module also holds qe_fp_count / qe_fp_write (count + direct ordered write)
     bool dense = false;          // the module holds the dense single-pass kernel only (entry qe_fused)
+    bool has_probe = false;      // the module holds qe_conj_probe (pass rate of every conjunct on its own)
+    int nconj = 0;               // conjuncts of the filter's top-level AND chain (0: not staged)
+    std::vector<std::vector<int>> conj_cols;   // per conjunct, in EVALUATION order: the kernel column slots it reads
+    std::vector<int> col_width;  // bytes per row of every kernel column slot (0: bitmap)
     int fl_ring = 0;             // local form (qe_fl_scan / qe_fl_move): rows per chunk slot = LDS entries per wave
     std::vector<std::vector<int32_t>> aux_tables;   // int32 tables indexed by dictionary codes (string ranks, remaps): col[kMaxCols-1-k]
     // group-by mode: key columns of the result, their domain sizes (without the extra NULL code) and the
@@ -266,6 +285,8 @@ struct Plan {
     mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
     mutable int64_t id_capacity = 0;          // .. of the key -> dense id table (qe_ht_build)
     mutable bool use_ids = false;             // .. the keys did not fit the LDS table last time: resolve them to dense ids first
+    mutable std::vector<int> conj_order;      // filter+project: evaluation order of the conjuncts chosen from measured pass rates (empty: as written)
+    mutable bool conj_decided = false;
     mutable bool local_overflowed = false;    // filter+project: a chunk of the local form kept more rows than its slot holds: never again
     int est_regs = 0;                         // register estimate of the plan's geometry (get_plan)
     bool explicit_geometry = false;           // unroll / chunk / ring were fixed through qe_options.tuning
@@ -324,4 +345,25 @@ struct qe_ctx {
     void *comm = nullptr;
     int comm_rank = -1, comm_nranks = 0;
     int last_form = -1;   // QE_FORM_* of the last qe_filter_project execution
+    // result -> host (qe_result_to_host): a second stream, so that the copy of one batch's result runs beside the scan of the
+    // next batch, and pinned staging owned by the context
+    hipStream_t copy_stream = nullptr;
+    qe::PinnedPool pinned;
+    std::vector<struct qe_host_result *> host_results;   // alive host results (their copies may still read a qe_result)
+};
+
+struct qe_host_result {
+    const qe_result *src = nullptr;    // the device result the copies read; nullptr once they have completed
+    int64_t count = 0;
+    struct Col {
+        int type = 0;
+        bool nullable = false;
+        void *data = nullptr;          // pinned host memory
+        uint64_t *validity = nullptr;  // pinned host memory or null
+        std::shared_ptr<qe::DictData> dict;
+        qe_dict dict_handle;
+    };
+    std::vector<Col> cols;
+    hipEvent_t done = nullptr;
+    bool waited = false;
 };

@@ -336,10 +336,84 @@ class Result:
     def to_columns(self) -> List[Column]:
         return [self.column_to_host(i) for i in range(self.ncols)]
 
+    def to_host(self) -> "HostResult":
+        """qe_result_to_host: START copying every column into pinned host memory owned by the library (copy stream) and
+        return at once; HostResult.wait() blocks until the bytes are there."""
+        h = C.c_void_p()
+        N.check(self.ctx.handle, self.ctx._lib.qe_result_to_host(self.ctx.handle, self.handle, C.byref(h)))
+        return HostResult(self.ctx, h, self)
+
     def free(self) -> None:
         if self.handle and self.ctx.handle:
             self.ctx._lib.qe_result_free(self.ctx.handle, self.handle)
         self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostResult:
+    """qe_host_result: the columns of a result in PINNED host memory owned by the library (zero-copy numpy views)."""
+
+    def __init__(self, ctx: Context, handle, source: Result):
+        self.ctx = ctx
+        self.handle = handle
+        self._source = source        # the device result must outlive the copies
+
+    def wait(self) -> "HostResult":
+        N.check(self.ctx.handle, self.ctx._lib.qe_host_result_wait(self.ctx.handle, self.handle))
+        self._source = None
+        return self
+
+    @property
+    def count(self) -> int:
+        return int(self.ctx._lib.qe_host_result_count(self.handle))
+
+    @property
+    def ncols(self) -> int:
+        return int(self.ctx._lib.qe_host_result_ncols(self.handle))
+
+    def column_views(self, col: int):
+        """(values, validity words | None) as numpy arrays VIEWING the pinned buffers (valid until free()); BOOLEAN values
+        and validity are bitmap words (row i = word i >> 6, bit i & 63)."""
+        self.wait()
+        v = N.ColView()
+        N.check(self.ctx.handle, self.ctx._lib.qe_host_result_column(self.handle, col, C.byref(v)))
+        t = DataType(v.type)
+        n = int(v.count)
+        nwords = (n + 63) // 64
+
+        def view(ptr, npdt, cnt):
+            if cnt == 0 or not ptr:
+                return np.zeros(0, dtype=npdt)
+            buf = (C.c_char * (cnt * np.dtype(npdt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=npdt, count=cnt)
+        data = view(v.data, np.uint64, nwords) if t == DataType.BOOLEAN else view(v.data, _NP[t], n)
+        valid = view(v.validity, np.uint64, nwords) if v.validity else None
+        return data, valid
+
+    def column(self, col: int) -> Column:
+        """A Column that OWNS its data (copied out of the pinned buffers), for tests."""
+        data, valid = self.column_views(col)
+        v = N.ColView()
+        N.check(self.ctx.handle, self.ctx._lib.qe_host_result_column(self.handle, col, C.byref(v)))
+        t = DataType(v.type)
+        n = int(v.count)
+        vals = unpack_bitmap(data, n) if t == DataType.BOOLEAN else data.copy()
+        dictionary = None
+        if t == DataType.STRING:
+            m = self.ctx._lib.qe_dict_size(v.dict)
+            dictionary = [self.ctx._lib.qe_dict_entry(v.dict, i).decode("utf-8") for i in range(m)]
+        return Column(t, vals, unpack_bitmap(valid, n) if valid is not None else None, dictionary)
+
+    def free(self) -> None:
+        if self.handle and self.ctx.handle:
+            self.ctx._lib.qe_host_result_free(self.ctx.handle, self.handle)
+        self.handle = None
+        self._source = None
 
     def __del__(self):
         try:
@@ -371,6 +445,17 @@ def chosen_geometry(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledE
                                                             _expr_array(projections), len(projections), C.byref(chosen),
                                                             C.byref(cached)))
     return int(chosen.value), bool(cached.value)
+
+
+def conjunct_order(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],
+                   projections: Sequence[CompiledExpression]):
+    """qe_filter_project_conjunct_order: None while the plan has not measured its conjuncts yet, else the list of written-order
+    indices in evaluation order."""
+    order = (C.c_int32 * 16)()
+    n = C.c_int32()
+    N.check(ctx.handle, ctx._lib.qe_filter_project_conjunct_order(ctx.handle, batch.handle, filter.handle if filter else None,
+                                                                  _expr_array(projections), len(projections), order, 16, C.byref(n)))
+    return None if n.value < 0 else [int(order[i]) for i in range(min(n.value, 16))]
 
 
 def generated_source(ctx: Context, batch: DeviceBatch, filter: Optional[CompiledExpression],

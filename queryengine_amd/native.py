@@ -106,6 +106,12 @@ SYMBOLS = [
     ("qe_result_column", C.c_int32, [_P, C.c_int32, C.POINTER(ColView)]),
     ("qe_result_column_to_host", C.c_int32, [_P, _P, C.c_int32, _P, _P]),
     ("qe_result_free", None, [_P, _P]),
+    ("qe_result_to_host", C.c_int32, [_P, _P, C.POINTER(_P)]),
+    ("qe_host_result_wait", C.c_int32, [_P, _P]),
+    ("qe_host_result_count", C.c_int64, [_P]),
+    ("qe_host_result_ncols", C.c_int32, [_P]),
+    ("qe_host_result_column", C.c_int32, [_P, C.c_int32, C.POINTER(ColView)]),
+    ("qe_host_result_free", None, [_P, _P]),
     ("qe_result_concat", C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(_P)]),
     ("qe_result_order_by", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
     ("qe_comm_unique_id", C.c_int32, [_P, _P]),
@@ -117,6 +123,7 @@ SYMBOLS = [
     ("qe_comm_allgather_host", C.c_int32, [_P, _P, C.c_size_t, _P]),
     ("qe_filter_project_source", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_char_p)]),
     ("qe_filter_project_geometry", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("qe_filter_project_conjunct_order", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     ("qe_stream_read_bandwidth", C.c_int32, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     ("qe_stream_read_write_time", C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 ]

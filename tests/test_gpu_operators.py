@@ -492,3 +492,48 @@ def test_order_by_query_sorts_on_the_device(gpu_ctx):
     from queryengine_amd.operators import _compare_key
     exp.sort(key=lambda r: _compare_key(r[1]))
     assert rows == exp and rows[0][1] is None
+
+
+def test_result_to_host_pinned_path_returns_the_same_bytes(gpu_ctx):
+    """qe_result_to_host (pinned staging owned by the library, copy stream, asynchronous start) hands out the same bytes as
+    the column-by-column copy into caller buffers -- nullable INT64 / DOUBLE, BOOLEAN bitmaps, dictionary codes, an empty
+    result -- also when the next scan runs while the copy is in flight, when the device result is freed before the wait,
+    and when the pinned buffers are recycled."""
+    from queryengine_amd import engine as E
+    from queryengine_amd import workloads as W
+    from helpers import D, I64, S, Fn, assert_columns_equal, col, fn, num
+    ctx = gpu_ctx
+    wl = W.config2(3_000_011, null_pct=1)
+    projs = list(wl.projections) + [fn(Fn.CMP_LT, col("c", 2, D), num(0.25)), fn(Fn.CMP_GT, col("b", 1, I64), num(7))]
+    batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], wl.default_rows)
+    cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in projs]
+    for rnd in range(3):                                  # round 2 and 3 run on recycled pinned buffers
+        res = E.filter_project(ctx, batch, cf, cp)
+        want = res.to_columns()
+        host = res.to_host()                              # copies started, not waited for
+        other = E.filter_project(ctx, batch, cf, cp)      # the next scan beside the copy
+        assert other.count == res.count
+        other.free()
+        if rnd == 1:
+            res.free()                                    # waits for the copy that still reads it
+        host.wait()
+        assert host.count == len(want[0]) and host.ncols == len(want)
+        for i, w in enumerate(want):
+            assert_columns_equal(host.column(i), w, f"round {rnd} column {i}")
+        data, valid = host.column_views(0)                # zero-copy views of the pinned memory
+        assert data.dtype == np.int64 and len(data) == host.count and valid is not None
+        host.free()
+        res.free()
+    # dictionary codes keep their dictionary; an empty result works
+    wl4 = W.config4(200_000, nkeys=10, key="k0004")
+    b4 = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl4.columns], wl4.default_rows)
+    r4 = E.filter_project(ctx, b4, ctx.compile(wl4.filter), [ctx.compile(p) for p in wl4.projections])
+    h4 = r4.to_host().wait()
+    for i, w in enumerate(r4.to_columns()):
+        assert_columns_equal(h4.column(i), w, f"cfg 4 column {i}")
+    h4.free(); r4.free()
+    r0 = E.filter_project(ctx, b4, ctx.compile(fn(Fn.CMP_EQ, col("s", 0, S), __import__("queryengine_amd").StringLiteralExpression("absent"))),
+                          [ctx.compile(p) for p in wl4.projections])
+    h0 = r0.to_host().wait()
+    assert h0.count == 0 and len(h0.column(1).data) == 0
+    h0.free(); r0.free(); b4.free(); batch.free()

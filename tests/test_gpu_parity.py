@@ -648,3 +648,57 @@ def test_geometry_choice_on_a_large_batch(oracle, tmp_path):
     _workload_vs_oracle(ctx2, oracle, wl, n, reps=1)       # runs the persisted geometry at once
     assert E.chosen_geometry(ctx2, batch2, cf2, cp2) == (chosen, True)
     ctx2.close()
+
+
+def test_conjuncts_are_ordered_by_measured_pass_rate(oracle):
+    """`c < 0.5 AND a < 100` loads c for every row and a for half of them when evaluated as written; on its first execution on a
+    large batch the plan measures every conjunct's pass rate and evaluates `a < 100` (passes 10 %) first, like the same filter
+    written the other way round.  Same rows either way (a row is kept iff every conjunct is TRUE: FilterOperator.kt:20), bit
+    for bit against the written-order plan, the oracle on two windows, and with the ordering switched off (debug bit
+    1048576).  Nullable inputs: a NULL conjunct drops the row whatever the order."""
+    from queryengine_amd import workloads as W
+    n = 9_000_017
+    wl = W.config2(n, null_pct=1)
+    A_, B_, C_ = col("a", 0, I64), col("b", 1, I64), col("c", 2, D)
+    swapped = fn(Fn.AND, fn(Fn.CMP_LT, C_, num(0.5)), fn(Fn.CMP_LT, A_, num(100)))
+    three = fn(Fn.AND, fn(Fn.AND, fn(Fn.CMP_LT, C_, num(0.9)), fn(Fn.CMP_GE, B_, num(0))), fn(Fn.CMP_LT, A_, num(50)))
+    results = {}
+    for name, tuning in (("ordered", []), ("as_written", [0, 0, 0, 0, 0, 1048576])):
+        ctx = E.Context(device=0, tuning=tuning)
+        batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n)
+        cp = [ctx.compile(p) for p in wl.projections]
+        for label, flt, want_order in (("written", wl.filter, [0, 1]), ("swapped", swapped, [1, 0]), ("three", three, [2, 0, 1])):
+            cf = ctx.compile(flt)
+            assert E.conjunct_order(ctx, batch, cf, cp) is None
+            res = E.filter_project(ctx, batch, cf, cp)
+            order = E.conjunct_order(ctx, batch, cf, cp)
+            if name == "ordered":
+                assert order == want_order, (label, order)
+            else:
+                assert order is None
+            again = E.filter_project(ctx, batch, cf, cp)
+            cols, cols2 = res.to_columns(), again.to_columns()
+            for g, w in zip(cols, cols2):
+                assert_columns_equal(g, w, f"{name} {label}: second execution")
+            results[name, label] = cols
+            res.free(); again.free()
+        if name == "ordered":
+            m = 80_000
+            for begin in (0, (n - 200_000) - (n - 200_000) % 64):
+                host = [batch.column_to_host(j, begin, m) for j in range(batch.ncols)]
+                want = oracle.filter_project(host, swapped, wl.projections, oracle.BYTECODE_COMPILER)
+                nsel = 0
+                if begin:   # kept rows in front of the window: an independent aggregate COUNT over rows [0, begin)
+                    head = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], begin)
+                    _, nsel = E.filter_aggregate(ctx, head, ctx.compile(swapped), [ctx.compile(A_)], [N.AGG_COUNT])
+                    head.free()
+                lo, k = int(nsel), len(want[0])
+                for g, w in zip(results[name, "swapped"], want):
+                    assert_columns_equal(Column(g.type, g.data[lo:lo + k], None if g.valid is None else g.valid[lo:lo + k]), w, f"window at {begin}")
+        batch.free()
+        ctx.close()
+    for label in ("written", "swapped", "three"):
+        for g, w in zip(results["ordered", label], results["as_written", label]):
+            assert_columns_equal(g, w, f"{label}: ordered vs as written")
+    for g, w in zip(results["ordered", "written"], results["ordered", "swapped"]):
+        assert_columns_equal(g, w, "written vs swapped")
