@@ -122,8 +122,9 @@ GATHER_TIMEOUT_S = 120
 CFG5_ROWS_PER_GPU = 10_000_000_000 // 8      # BASELINE.json configs[4]
 
 
-def traffic_key(workload: str, rows: int, selectivity, exec_mode: str) -> str:
-    return f"{workload}|rows={rows}|sel={'default' if selectivity is None else format(selectivity, 'g')}|{exec_mode}"
+def traffic_key(workload: str, rows: int, selectivity, exec_mode: str, null_pct: int = 0) -> str:
+    return (f"{workload}|rows={rows}|sel={'default' if selectivity is None else format(selectivity, 'g')}|{exec_mode}" +
+            (f"|null={null_pct}" if null_pct else ""))
 
 
 def code_hash(ctx, E, batch, cf, cp, exec_mode: str) -> str:
@@ -131,7 +132,8 @@ def code_hash(ctx, E, batch, cf, cp, exec_mode: str) -> str:
     h = hashlib.sha1()
     if exec_mode == "fused":   # the plan's generated source + the generator itself (the dense / two-pass forms come from it too)
         h.update(E.generated_source(ctx, batch, cf, cp).encode())
-        h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", "qe_codegen.cpp"), "rb").read())
+        for f in ("qe_codegen.cpp", "qe_api.cpp"):   # the generator, and the executor that picks form / order / geometry
+            h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", f), "rb").read())
         return h.hexdigest()[:16]
     for f in ("qe_pernode.cpp", "qe_pernode_kernels.hip"):
         h.update(open(os.path.join(ROOT, "queryengine_amd", "csrc", f), "rb").read())
@@ -150,11 +152,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)   # the first executions of a plan also time its kernel geometries
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: see the module docstring)")
-    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config4"])
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config4", "config2_swapped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", default="", help="comma separated kernel tuning knobs (qe_options.tuning, DESIGN.md 3.1a)")
     ap.add_argument("--exec-mode", default="fused", choices=["fused", "per_node"])
     ap.add_argument("--selectivity", type=float, default=None, help="config2 only: target selectivity (changes the literals)")
+    ap.add_argument("--null-pct", type=int, default=0, help="config2 only: ~this % of NULLs in every input column (validity bitmaps "
+                    "are read, nullable outputs are packed): SURVEY 8(d)'s nullable variant")
     ap.add_argument("--gather", action="store_true", help="time the materialising exchange too (default when --gpus > 1)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--profile-run", action="store_true",
@@ -191,14 +195,16 @@ def main():
 
     if args.rows is None:
         args.rows = W.WORKLOADS[args.workload]().default_rows
-        if world > 1 and args.workload == "config2":
+        if world > 1 and args.workload in ("config2", "config2_swapped"):
             args.rows = CFG5_ROWS_PER_GPU
     wl = W.WORKLOADS[args.workload](args.rows)
     if args.selectivity is not None and args.workload == "config2":
         # a < 1000 * s / c_limit with c < c_limit: sweep 1 %, 10 %, 50 %, 100 % as BASELINE.md section 3 asks
         s_ = max(0.0, min(1.0, args.selectivity))
         c_limit = 0.5 if s_ <= 0.5 else 1.0
-        wl = W.config2(args.rows, a_limit=round(1000 * s_ / c_limit), c_limit=c_limit)
+        wl = W.config2(args.rows, a_limit=round(1000 * s_ / c_limit), c_limit=c_limit, null_pct=args.null_pct)
+    elif args.null_pct and args.workload in ("config2", "config2_swapped"):
+        wl = W.WORKLOADS[args.workload](args.rows, null_pct=args.null_pct)
     tuning = [int(x) for x in args.tuning.split(",") if x]
     ctx = E.Context(device=local_rank, profile=True, tuning=tuning,
                     exec_mode=N.EXEC_FUSED if args.exec_mode == "fused" else N.EXEC_PER_NODE)
@@ -306,7 +312,7 @@ def main():
                 stream_gbps = None
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate passes; tools/profile_all.sh) -- reported only when it was collected on this workload AND this code
-        key = traffic_key(wl.name, nrows, args.selectivity, args.exec_mode)
+        key = traffic_key(wl.name, nrows, args.selectivity, args.exec_mode, args.null_pct)
         chash = code_hash(ctx, E, batch, cf, cp, args.exec_mode)
         traffic, traffic_src, traffic_stale = None, None, None
         try:
@@ -319,7 +325,12 @@ def main():
                     traffic_stale = f"profiles/traffic.json holds {key} for code {ent.get('code_hash')}, this run is {chash}"
         except Exception:
             pass
-        dense = args.exec_mode == "fused" and wl.filter is not None and nout >= 0.12 * nrows
+        conj_order = None
+        if args.exec_mode == "fused" and cf is not None:
+            try:
+                conj_order = E.conjunct_order(ctx, batch, cf, cp)   # written-order indices of the filter's conjuncts in evaluation order
+            except Exception:
+                conj_order = None
         geometry = None
         if args.exec_mode == "fused":   # which of the plan's two kernel geometries the measured choice kept (and whether it came from the JIT cache)
             try:
@@ -347,8 +358,14 @@ def main():
                          "traffic_gbps": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic and kernel_ms > 0 else None,
                          # the honest second fraction: bytes the kernel really MOVED (PMC) / kernel time / peak
                          "frac_moved": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic and kernel_ms > 0 else None,
-                         "kernel": ("qe_fused (dense single-pass form, chosen from selectivity 0.12 on)" if dense else
-                                    "qe_fused (LDS-ring single-pass form)" if args.exec_mode == "fused" else "per-node kernels"),
+                         "kernel": ({N.FORM_DENSE: "qe_fused (dense single-pass form, chosen from selectivity 0.12 on)",
+                                     N.FORM_RING: "qe_fused (LDS-ring single-pass form)",
+                                     N.FORM_LOCAL: "qe_fl_scan + scan + qe_fl_move (local form: dependency-free scan into per-chunk slots, "
+                                                   "chosen up to selectivity 0.03; kernel_ms covers all of them)",
+                                     N.FORM_TWO_PASS: "qe_fp_count + scan + qe_fp_write (two-pass form)",
+                                     N.FORM_NO_FILTER: "qe_fused (projection only)"}.get(ctx.last_form, "qe_fused")
+                                    if args.exec_mode == "fused" else "per-node kernels"),
+                         "conjunct_order": conj_order,
                          "kernel_ms": kernel_ms, "kernel_ms_median": median(kern_ms), "kernel_ms_min": min(kern_ms) if kern_ms else None,
                          "geometry": geometry,
                          "note": "achieved = SURVEY 8(d) algorithmic bytes (every input column in full + output rows) / kernel time; "

@@ -747,6 +747,8 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
             plan->cg = generate_fused_source(in);
             plan->kernel = ctx->jit->get(plan->cg.source, "qe_fused", false);   // compile (or cache hit) only
             if (ctx->jit->last_scratch <= 0) break;
+            const bool can_retry = in.geo.min_waves > 1 || (in.geo.unroll > 2 && ctx->opts.tuning[1] == 0);
+            if (can_retry) ctx->jit->reject(plan->cg.source, ctx->jit->last_scratch);   // superseded below: it does not stay in the cache
             if (in.geo.min_waves > 2) {
                 in.geo.min_waves--;
             } else if (in.geo.unroll > 2 && ctx->opts.tuning[1] == 0) {
@@ -1491,9 +1493,12 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
                               const int32_t *agg_fns, int32_t nagg) {
     const CodegenOutput &cg = plan.cg;
     const bool ids_allowed = (ctx->opts.tuning[5] & 131072) == 0 && batch->nrows < (1ll << 32);   // debug bit 131072: keep the global-atomic form
-    if (plan.use_ids && ids_allowed) {
+    bool ids_failed = plan.ids_overflow;   // more keys than a dense table takes, found out by an earlier execution: straight to the global-atomic form
+    if (plan.use_ids && ids_allowed && !ids_failed) {
         qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
         if (r) return r;
+        plan.ids_overflow = ids_failed = true;
+        plan.use_ids = false;
     }
     const int W = cg.hash_words, NK = (int)cg.keys.size(), ACC = 2 + NK;
     if (W > 40) fail(QE_ERR_UNSUPPORTED, "too many GROUP BY keys + aggregates for one hash entry");
@@ -1506,7 +1511,6 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
         init.word[ACC + 2 + 2 * i] = agg_fns[i] == QE_AGG_MIN ? 0x7fffffffffffffffull : agg_fns[i] == QE_AGG_MAX ? 0x8000000000000000ull : 0ull;
     std::vector<unsigned long long> dense;
     int64_t m = 0;
-    bool ids_failed = false;
     if (n > 0) {
         int64_t C = plan.hash_capacity > 0 ? plan.hash_capacity : (1ll << 16);
         for (;;) {
@@ -1533,7 +1537,9 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
                 plan.use_ids = true;
                 qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
                 if (r) return r;
-                ids_failed = true;   // more keys than a dense table takes: the global-atomic form after all
+                ids_failed = true;   // more keys than a dense table takes: the global-atomic form after all -- and remembered,
+                plan.ids_overflow = true;   // so that later executions do not run the failing id build again
+                plan.use_ids = false;
                 continue;
             }
             collect_time(ctx);
@@ -1547,7 +1553,7 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             // more than a few dozen keys: probing the LDS table costs more than resolving ids first (300 keys: 15 ms here,
             // 6.6 ms as build pass + dense LDS group-by; crossover ~70 keys) -- the next executions of this plan go that way
             static const int64_t ids_from = std::getenv("QE_IDS_FROM") ? std::atoll(std::getenv("QE_IDS_FROM")) : 64;
-            if (used > ids_from && ids_allowed) plan.use_ids = true;
+            if (used > ids_from && ids_allowed && !plan.ids_overflow) plan.use_ids = true;
             unsigned long long *d_dense = (unsigned long long *)ctx->pool.alloc((size_t)std::max<int64_t>(used, 1) * W * 8);
             struct G2 { qe_ctx *c; void *p; ~G2() { c->pool.release(p); } } g2{ctx, d_dense};
             QE_HIP(hipMemsetAsync(ctx->d_ctrl, 0, 16, ctx->stream));

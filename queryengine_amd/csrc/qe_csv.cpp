@@ -205,7 +205,9 @@ int32_t qe_csv_parse(qe_ctx *ctx, const char *data, size_t nbytes, int32_t nfiel
                 for (size_t i = 0; i < rec.size(); i++) {
                     const char *p; size_t n;
                     text(rec[i], p, n);
-                    if (n == std::strlen(names[k]) && std::memcmp(p, names[k], n) == 0) { idx[(size_t)k] = (int)i; break; }
+                    // a duplicated header name resolves to its LAST occurrence: commons-csv 1.8 (CSVFormat.DEFAULT allows
+                    // duplicates) fills its header map with put(), so a later column replaces an earlier one of the same name
+                    if (n == std::strlen(names[k]) && std::memcmp(p, names[k], n) == 0) idx[(size_t)k] = (int)i;
                 }
             }
             break;

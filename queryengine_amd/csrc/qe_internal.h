@@ -261,6 +261,7 @@ public:
     ~Jit();
     // compile (or fetch from memory / disk cache) and load; needs a current device unless load == false
     Kernel get(const std::string &source, const char *entry, bool load = true);
+    void reject(const std::string &source, int scratch);   // drop a spilling code object from the cache, keep the verdict
     static std::vector<char> compile(const std::string &source);
     static std::string source_key(const std::string &source);
     // persisted measured decisions (geometry choice) next to the code object; -1 = none
@@ -285,6 +286,7 @@ struct Plan {
     mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
     mutable int64_t id_capacity = 0;          // .. of the key -> dense id table (qe_ht_build)
     mutable bool use_ids = false;             // .. the keys did not fit the LDS table last time: resolve them to dense ids first
+    mutable bool ids_overflow = false;        // .. more than 2^20 - 1 distinct keys: the id build cannot hold them, never try it again
     mutable std::vector<int> conj_order;      // filter+project: evaluation order of the conjuncts chosen from measured pass rates (empty: as written)
     mutable bool conj_decided = false;
     mutable bool local_overflowed = false;    // filter+project: a chunk of the local form kept more rows than its slot holds: never again

@@ -114,6 +114,30 @@ void Jit::store_choice(const std::string &source, int chosen, const std::string 
     else std::remove(tmp.c_str());
 }
 
+// A code object the plan builder REJECTED (it spills: get_plan lowers the occupancy request / the sub-tile and generates
+// again) does not stay in the cache -- a cache that keeps rejected objects invites a wrong hit after a key change.  What
+// stays is a marker with the measured scratch size, so that the next process learns the verdict without compiling again.
+void Jit::reject(const std::string &source, int scratch) {
+    const std::string key = source_key(source);
+    auto it = loaded_.find(key);
+    if (it != loaded_.end()) {
+        if (it->second.module) (void)hipModuleUnload(it->second.module);
+        loaded_.erase(it);
+    }
+    if (cache_dir_.empty()) return;
+    const std::string base = cache_dir_ + "/" + key;
+    std::remove((base + ".hsaco").c_str());
+    std::remove((base + ".hip").c_str());
+    std::remove((base + ".geo").c_str());
+    const std::string tmp = base + ".rej.tmp" + std::to_string((long)::getpid());
+    std::ofstream f(tmp);
+    if (!f) return;
+    f << scratch << "\n";
+    f.close();
+    if (f.good()) std::rename(tmp.c_str(), (base + ".rej").c_str());
+    else std::remove(tmp.c_str());
+}
+
 Kernel Jit::get(const std::string &source, const char *entry, bool load) {
     const std::string key = source_key(source);
     auto it = loaded_.find(key);
@@ -121,6 +145,17 @@ Kernel Jit::get(const std::string &source, const char *entry, bool load) {
         mem_hits++;
         last_scratch = it->second.scratch;
         return it->second;
+    }
+    if (!load && !cache_dir_.empty()) {   // a verdict of an earlier process: this source spills
+        std::ifstream rj(cache_dir_ + "/" + key + ".rej");
+        int sc = 0;
+        if (rj && (rj >> sc) && sc > 0) {
+            Kernel k;
+            k.scratch = sc;
+            last_scratch = sc;
+            disk_hits++;
+            return k;
+        }
     }
     std::vector<char> code;
     std::string path;

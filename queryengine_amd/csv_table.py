@@ -74,7 +74,7 @@ def read_csv_columns(path: str, schema: Schema, projection: Optional[Sequence[st
             header = []
         hmap: Dict[str, int] = {}
         for i, h in enumerate(header):
-            hmap.setdefault(h, i)
+            hmap[h] = i          # a duplicated header resolves to its LAST occurrence (commons-csv 1.8 builds its map with put())
         idx = []
         for f in fields:
             if f.name not in hmap:

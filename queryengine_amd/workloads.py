@@ -122,4 +122,15 @@ def config4(nrows: int = 1_000_000_000, nkeys: int = 1000, key: str = "k0042") -
                     _fn(Fn.CMP_EQ, s, StringLiteralExpression(key), t=B), [s, v], nrows, 1.0 / nkeys)
 
 
-WORKLOADS = {"config1": config1, "config2": config2, "config3": config3, "config4": config4}
+def config2_swapped(nrows: int = 1_000_000_000, null_pct: int = 0) -> Workload:
+    """config 2 with its conjuncts written the other way round: SELECT a + b, c * 2.0 FROM t WHERE c < 0.5 AND a < 100.
+    Evaluated as written it loads c in full and a for half of the rows; the plan's measured conjunct order makes it config 2."""
+    wl = config2(nrows, null_pct=null_pct)
+    a, c = wl.filter.operands[0], wl.filter.operands[1]
+    wl.filter = _fn(Fn.AND, c, a, t=B)
+    wl.name = "config2_swapped"
+    wl.sql = "SELECT a + b, c * 2.0 FROM t WHERE c < 0.5 AND a < 100"
+    return wl
+
+
+WORKLOADS = {"config1": config1, "config2": config2, "config3": config3, "config4": config4, "config2_swapped": config2_swapped}

@@ -98,6 +98,15 @@ def test_native_csv_parser_matches_the_python_restatement(tmp_path, native_lib):
     assert ok[0] == 3.0 and ok[1] == 7.0 and math.isnan(ok[2]) and ok[3] == float("inf")
     with pytest.raises(Exception):
         read_csv_native(ctx, b'a\n"unterminated\n', Schema([Field("a", S)]))
+    # a duplicated header name resolves to its LAST occurrence: commons-csv 1.8's CSVFormat.DEFAULT allows duplicate headers
+    # and fills its header map with put() (a later column replaces an earlier one).  Self-derived expectation: the library is
+    # not in the image and the reference holds no fixture with duplicate headers -- parity unpinned.
+    dup = b"x,y,x\n1,2,3\n4,5,\n"
+    sch = Schema([Field("x", D), Field("y", D)])
+    pd_ = tmp_path / "dup.csv"
+    pd_.write_bytes(dup)
+    for t2 in (read_csv_native(ctx, dup, sch), read_csv_columns(str(pd_), sch)):
+        assert t2.column("x").to_list() == [3.0, None] and t2.column("y").to_list() == [2.0, 5.0]
     ctx.close()
 
 

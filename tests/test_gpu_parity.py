@@ -328,6 +328,46 @@ def test_full_size_1b_rows_properties(gpu_ctx, oracle):
     gpu_ctx.trim()
 
 
+def test_full_size_1b_rows_nullable_properties(gpu_ctx, oracle):
+    """SURVEY 8(d)'s nullable variant of config 2 at its full size (1 B rows, ~1 % NULLs in every input column: validity bitmaps
+    read, nullable outputs packed) through the workload object bench.py runs with --null-pct 1, plus a global-row-id column.
+    Row ids strictly increasing; count == an independent aggregate COUNT of the kept rows; the NULLs of every output column
+    == kept rows - the aggregate COUNT(<that expression>) (COUNT skips NULLs: Accumulators.kt:26-36) -- a NULL b under a kept
+    row must give a NULL a + b, never drop the row; the expected selectivity 0.05 * 0.99^2; two windows walked by the oracle."""
+    from queryengine_amd import workloads as W
+    n = 1_000_000_000
+    wl = W.config2(n, null_pct=1)
+    rid_spec = N.GenSpec(); rid_spec.kind = N.GEN_I64_ROWID; rid_spec.col_id = 99
+    batch = E.DeviceBatch.generate(gpu_ctx, [c.spec(gpu_ctx) for c in wl.columns] + [rid_spec], n)
+    R_ = col("rowid", 3, I64)
+    proj_exprs = list(wl.projections) + [R_]
+    cf, cp = gpu_ctx.compile(wl.filter), [gpu_ctx.compile(p) for p in proj_exprs]
+    r1 = E.filter_project(gpu_ctx, batch, cf, cp)
+    cols1 = r1.to_columns()
+    rid = cols1[-1].data
+    assert abs(r1.count / n - 0.05 * 0.99 * 0.99) < 0.0005
+    assert np.all(np.diff(rid) > 0) and rid[0] >= 0 and rid[-1] < n
+    vals, nsel = E.filter_aggregate(gpu_ctx, batch, cf, cp, [N.AGG_COUNT] * len(cp))
+    assert nsel == r1.count == int(vals[-1])
+    for i, c in enumerate(cols1[:-1]):
+        nulls = 0 if c.valid is None else int((~c.valid).sum())
+        assert nulls == r1.count - int(vals[i]), f"output {i}: {nulls} NULLs, aggregate says {r1.count - int(vals[i])}"
+    assert int((~cols1[0].valid).sum()) > 0.005 * r1.count        # a + b is NULL where b is (a passed the filter: not NULL)
+    assert cols1[1].valid is None or bool(cols1[1].valid.all())   # c * 2.0: c passed the filter, never NULL under a kept row
+    for begin in (0, (n - 700_000) - (n - 700_000) % 64):
+        m = 600_000
+        win = [batch.column_to_host(j, begin, m) for j in range(4)]
+        want = oracle.filter_project(win, wl.filter, proj_exprs, oracle.BYTECODE_COMPILER)
+        lo = int(np.searchsorted(rid, begin))
+        k = len(want[0])
+        assert k > 0 and np.array_equal(rid[lo:lo + k], want[-1].data)
+        for g, w in zip(cols1[:-1], want[:-1]):
+            gv = None if g.valid is None else g.valid[lo:lo + k]
+            assert_columns_equal(Column(g.type, g.data[lo:lo + k], gv), w, f"nullable cfg 2 window at {begin}")
+    r1.free(); batch.free()
+    gpu_ctx.trim()
+
+
 def test_cfg5_rank7_shard_properties(gpu_ctx, oracle):
     """BASELINE configs[4] ("cfg 5": 10 B rows row-range sharded over 8 GPUs), the single-GPU half of it: RANK 7's shard --
     1.25 B rows whose GLOBAL row ids start at 7 x 1.25 B = 8.75e9 > 2^33 -- through the very workload object bench.py runs at

@@ -6,7 +6,7 @@
 # Raw output -> gpurun_out/prof_<tag>/<case>/ ; tools/summarize_profile.py condenses it into profiles/.
 #   usage: tools/profile_all.sh <tag> [case ...]     (no case = all)
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -17,12 +17,14 @@ CASES[cfg2_sel001]="bench.py --workload config2 --selectivity 0.01"
 CASES[cfg2_sel010]="bench.py --workload config2 --selectivity 0.10"
 CASES[cfg2_sel050]="bench.py --workload config2 --selectivity 0.50"
 CASES[cfg2_sel100]="bench.py --workload config2 --selectivity 1.00"
+CASES[cfg2_null]="bench.py --workload config2 --null-pct 1"
+CASES[cfg2_swapped]="bench.py --workload config2_swapped"
 CASES[cfg3]="bench.py --workload config3"
 CASES[cfg4]="bench.py --workload config4"
 CASES[cfg2_pernode]="bench.py --workload config2 --exec-mode per_node"
 CASES[q6agg]="tools/bench_q6.py"
 CASES[groupby]="tools/bench_groupby.py 1000000000 1000,100000,1000000"
-ORDER="cfg2 cfg2_sel001 cfg2_sel010 cfg2_sel050 cfg2_sel100 cfg3 cfg4 cfg2_pernode q6agg groupby"
+ORDER="cfg2 cfg2_null cfg2_swapped cfg2_sel001 cfg2_sel010 cfg2_sel050 cfg2_sel100 cfg3 cfg4 cfg2_pernode q6agg groupby"
 [ $# -gt 0 ] && ORDER="$*"
 cd /tmp
 for C in $ORDER; do
