@@ -721,16 +721,17 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         // turns into HBM traffic (84 B/lane of scratch cost 2.7 GB of extra writes per 1 B rows when measured).
         auto dwords = [](int t) { return (t == QE_DOUBLE || t == QE_INT64) ? 2 : 1; };
         for (;;) {
-            int in_dw = 0, out_dw = 0, nbool = 1;
+            int in_dw = 0, out_dw = 0, nbool = 1, in_nulls = 0;
             for (int c : plan->cg.used_cols) {
                 in_dw += dwords(in.schema[c].type);
-                nbool += in.schema[c].nullable ? 1 : 0;
+                in_nulls += in.schema[c].nullable ? 1 : 0;
             }
             for (const OutSpec &o : plan->cg.outs) {
                 out_dw += dwords(o.type);
                 nbool += o.nullable ? 1 : 0;
             }
-            const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + 54;
+            // the validity bits of ALL nullable inputs share one register per load group (qe_vb)
+            const int est = 2 * in.geo.unroll * (std::max(in_dw, out_dw) + nbool - 1) + (in_nulls ? in.geo.unroll : 0) + 54;
             // three waves per SIMD need <= 168 VGPRs: a half-size sub-tile at 3 waves beat the full one at 2 waves
             // (cfg 2 with nullable inputs: 4.47 vs 6.16 ms per 1 B rows)
             plan->est_regs = est;
@@ -740,7 +741,8 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
                 plan->cg = generate_fused_source(in);
                 continue;
             }
-            in.geo.min_waves = est <= 128 ? 4 : est <= 168 ? 3 : est <= 256 ? 2 : 1;
+            // (nullable cfg 2, est 122: 3 waves per SIMD 3.54 ms, 4 waves 3.69 ms -- the request also shapes the register allocation)
+            in.geo.min_waves = est <= 120 ? 4 : est <= 168 ? 3 : est <= 256 ? 2 : 1;
             break;
         }
         for (;;) {
