@@ -607,6 +607,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
     in.debug_mask = ctx->opts.tuning[5] & 255;   // bits 256.. are host-side switches, not ablation builds
     in.staged = (ctx->opts.tuning[5] & 2048) == 0;
+    in.prefetch = (ctx->opts.tuning[5] & 2097152) ? 0 : (ctx->opts.tuning[5] & 4194304) ? 2 : 1;   // debug bits: 2097152 no stage-0 prefetch, 4194304 always
     in.dense = dense && filter != nullptr && !agg_fns;
     if (in.dense) {   // the dense kernel has its own shape: a workgroup per tile of QE_WAVES sub-tiles, one tile parked in LDS
         in.geo.subs_per_chunk = 1;
@@ -621,7 +622,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.filter_load_stages = (ctx->opts.tuning[5] & 4096) ? 1 : 0;   // bit 4096: every filter column in the first load stage   // bit 2048: load every column for every row (no late materialisation)
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << (in.dense ? "D" : "") << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "P" << in.prefetch << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (c.dict ? c.dict->id : 0) << ",";   // the dictionary's serial number, not its address
@@ -1073,7 +1074,13 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             lp.total = (unsigned long long *)(ctx->d_ctrl + 2);
             // 20 waves per CU: measured on cfg 3 (600 M rows) 12 / 16 / 20 / 24 waves per CU = 1.99 / 1.85 / 1.78 / 1.85 ms, on cfg 4
             // 0.665 / 0.654 / 0.661 / 0.670 ms -- past 20 the extra streams cost more than the extra loads in flight bring
-            const int bpc = ctx->opts.tuning[3] % 100 > 0 ? blocks_per_cu(ctx, *plan) : std::min(blocks_per_cu(ctx, *plan), std::max(1, 20 / waves));
+            int occ = 0;   // of qe_fl_scan itself (it has its own register allocation: no occupancy request, so that it never spills)
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, f_scan, plan->geo.threads, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                occ = 2;
+            }
+            occ = std::max(1, std::min(occ, 8));
+            const int bpc = ctx->opts.tuning[3] % 100 > 0 ? ctx->opts.tuning[3] % 100 : std::min(occ, std::max(1, 20 / waves));
             const int64_t max_grid = (int64_t)device_cus(ctx->device) * bpc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, max_grid));
             const int mgrid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)device_cus(ctx->device) * 8));

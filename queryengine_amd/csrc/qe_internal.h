@@ -204,6 +204,8 @@ struct CodegenInput {
     int nt_stores = 1;    // non-temporal stores for the output rows
     std::vector<int> conj_order;  // evaluation order of the filter's conjuncts (a permutation of their written order); empty = as written
     int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
+    int prefetch = 1;     // staged filter+project plans: the stage-0 loads of the next sub-tile are issued at the start of this one
+                          // (0 never, 1 plans with >= 4 load stages, 2 every staged plan)
     bool staged = true;   // late materialisation: evaluate the filter's AND chain conjunct by conjunct, load later columns for live rows only
     bool dense = false;   // filter+project only: generate the DENSE single-pass kernel (chunk == sub-tile, blocking look-back between
                           // evaluation and stores, rows go from the registers straight to their final position: no LDS ring, no

@@ -57,21 +57,25 @@ std::vector<char> Jit::compile(const std::string &source) {
     return code;
 }
 
-// Scratch (register spill) bytes per lane of the first kernel of a code object: the msgpack metadata
-// note carries ".private_segment_fixed_size" followed by a small unsigned integer.
+// Scratch (register spill) bytes per lane of a code object = the LARGEST of its kernels': the msgpack metadata note carries
+// ".private_segment_fixed_size" followed by a small unsigned integer once per kernel (the module of a plan holds several
+// entry points -- the probe, the single-pass kernel, the local form's scan ... -- and none of them may spill).
 int Jit::scratch_bytes(const std::vector<char> &code) {
     static const char key[] = ".private_segment_fixed_size";
     const size_t kl = sizeof(key) - 1;
+    int worst = -1;
     for (size_t i = 0; i + kl + 5 < code.size(); i++) {
         if (std::memcmp(code.data() + i, key, kl) != 0) continue;
         const unsigned char *p = (const unsigned char *)code.data() + i + kl;
-        if (p[0] < 0x80) return p[0];
-        if (p[0] == 0xcc) return p[1];
-        if (p[0] == 0xcd) return (p[1] << 8) | p[2];
-        if (p[0] == 0xce) return (int)(((unsigned)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]);
-        return -1;
+        int v = -1;
+        if (p[0] < 0x80) v = p[0];
+        else if (p[0] == 0xcc) v = p[1];
+        else if (p[0] == 0xcd) v = (p[1] << 8) | p[2];
+        else if (p[0] == 0xce) v = (int)(((unsigned)p[1] << 24) | (p[2] << 16) | (p[3] << 8) | p[4]);
+        worst = std::max(worst, v);
+        i += kl;
     }
-    return -1;
+    return worst;
 }
 
 // the compiler is part of a code object's identity: a cache directory that outlives a ROCm update must not serve stale code
