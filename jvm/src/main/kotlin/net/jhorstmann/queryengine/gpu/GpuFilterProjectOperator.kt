@@ -34,6 +34,7 @@ class GpuFilterProjectOperator(
     private val nproj = projections.size
     private var batch: MemorySegment = MemorySegment.NULL    // pinned to HBM once, reused by every open()
     private var result: MemorySegment = MemorySegment.NULL
+    private var hostResult: MemorySegment = MemorySegment.NULL   // qe_host_result*: the result's columns in pinned host memory
     private var columns: Array<HostColumn>? = null
     private var idx = 0L
     private var count = 0L
@@ -60,6 +61,11 @@ class GpuFilterProjectOperator(
         count = QeNative.qe_result_count.invokeExact(result) as Long
         columns = null
         idx = 0
+        // the rows' way to the host starts NOW, on the context's copy stream, into pinned memory owned by the library:
+        // it runs beside whatever the caller does before its first next() (and beside the next batch's scan)
+        val hout = arena.allocate(ADDRESS)
+        QeNative.check(ctx, QeNative.qe_result_to_host.invokeExact(ctx, result, hout) as Int)
+        hostResult = hout.get(ADDRESS, 0)
     }
 
     /** the qe_result* of the last open(): for a downstream GPU consumer (qe_gather, qe_result_order_by) */
@@ -68,12 +74,17 @@ class GpuFilterProjectOperator(
     override fun next(): Array<Any?>? {
         check(result != MemorySegment.NULL) { "Operator not initialized" }
         if (idx >= count) return null
-        val cols = columns ?: Array(nproj) { HostColumn.fetch(ctx, result, it, arena) }.also { columns = it }
+        val cols = columns ?: run {
+            QeNative.check(ctx, QeNative.qe_host_result_wait.invokeExact(ctx, hostResult) as Int)
+            Array(nproj) { HostColumn.view(ctx, hostResult, it, arena) }.also { columns = it }   // pinned memory: no second copy
+        }
         val i = idx++
         return Array(nproj) { cols[it].box(i) }                 // fresh row per call (ProjectionOperator.kt:18)
     }
 
     override fun close() {
+        if (hostResult != MemorySegment.NULL) QeNative.qe_host_result_free.invokeExact(ctx, hostResult)   // waits for a copy in flight
+        hostResult = MemorySegment.NULL
         if (result != MemorySegment.NULL) QeNative.qe_result_free.invokeExact(ctx, result)
         result = MemorySegment.NULL
         columns = null
@@ -83,7 +94,7 @@ class GpuFilterProjectOperator(
 /** One result column copied to the host; box() produces the reference's boxed values. */
 class HostColumn(val type: DataType?, val typeCode: Int, val data: MemorySegment, val validity: MemorySegment, val dict: List<String>?) {
     fun box(i: Long): Any? {
-        if ((validity.getAtIndex(JAVA_LONG, i shr 6) ushr (i and 63).toInt()) and 1L == 0L) return null
+        if (validity != MemorySegment.NULL && (validity.getAtIndex(JAVA_LONG, i shr 6) ushr (i and 63).toInt()) and 1L == 0L) return null
         return when (typeCode) {
             0 -> dict!![data.getAtIndex(JAVA_INT, i)]
             1 -> data.getAtIndex(JAVA_DOUBLE, i)
@@ -94,6 +105,26 @@ class HostColumn(val type: DataType?, val typeCode: Int, val data: MemorySegment
     }
 
     companion object {
+        /** Column `col` of a qe_host_result (after qe_host_result_wait): segments over the library's pinned buffers. */
+        fun view(ctx: MemorySegment, host: MemorySegment, col: Int, arena: Arena): HostColumn {
+            val v = arena.allocate(QeNative.COL_VIEW)
+            QeNative.check(ctx, QeNative.qe_host_result_column.invokeExact(host, col, v) as Int)
+            val type = v.get(JAVA_INT, 0)
+            val n = v.get(JAVA_LONG, 24)
+            val words = (n + 63) / 64
+            val width = when (type) { 1, 3 -> 8L; 2 -> 0L; else -> 4L }
+            val data = v.get(ADDRESS, 8).reinterpret(maxOf(8, if (type == 2) words * 8 else n * width))
+            val vptr = v.get(ADDRESS, 16)
+            // validity == NULL: no NULL in the column (box() checks for it)
+            val valid = if (vptr == MemorySegment.NULL) MemorySegment.NULL else vptr.reinterpret(maxOf(8, words * 8))
+            val dictSeg = v.get(ADDRESS, 32)
+            val dict = if (type == 0) (0 until (QeNative.qe_dict_size.invokeExact(dictSeg) as Int)).map {
+                (QeNative.qe_dict_entry.invokeExact(dictSeg, it) as MemorySegment).reinterpret(65536).getString(0)
+            } else null
+            return HostColumn(DataType.values().getOrNull(type), type, data, valid, dict)
+        }
+
+        /** Column `col` of a device result copied into caller-owned (arena) memory: qe_result_column_to_host. */
         fun fetch(ctx: MemorySegment, result: MemorySegment, col: Int, arena: Arena): HostColumn {
             val view = arena.allocate(QeNative.COL_VIEW)
             QeNative.check(ctx, QeNative.qe_result_column.invokeExact(result, col, view) as Int)

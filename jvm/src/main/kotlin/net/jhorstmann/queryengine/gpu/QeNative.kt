@@ -39,6 +39,14 @@ internal object QeNative {
     val qe_result_column = handle("qe_result_column", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS)
     val qe_result_column_to_host = handle("qe_result_column_to_host", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS)
     val qe_result_free = handle("qe_result_free", null, ADDRESS, ADDRESS)
+    // result -> PINNED host memory owned by the library (pooled per context), on the context's copy stream:
+    // qe_result_to_host STARTS the copies and returns; wait blocks; column gives HOST pointers in a qe_col_view
+    val qe_result_to_host = handle("qe_result_to_host", JAVA_INT, ADDRESS, ADDRESS, ADDRESS)          // ctx, result, qe_host_result**
+    val qe_host_result_wait = handle("qe_host_result_wait", JAVA_INT, ADDRESS, ADDRESS)
+    val qe_host_result_count = handle("qe_host_result_count", JAVA_LONG, ADDRESS)
+    val qe_host_result_ncols = handle("qe_host_result_ncols", JAVA_INT, ADDRESS)
+    val qe_host_result_column = handle("qe_host_result_column", JAVA_INT, ADDRESS, JAVA_INT, ADDRESS) // host, col, qe_col_view*
+    val qe_host_result_free = handle("qe_host_result_free", null, ADDRESS, ADDRESS)
     // ctx, qe_result*[nparts], nparts, qe_result** -> status: results of consecutive batches as ONE result (input order)
     val qe_result_concat = handle("qe_result_concat", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS)
     // ctx, result, column (0-based), qe_result** -> status: OrderByOperator.kt:9-15 on the device

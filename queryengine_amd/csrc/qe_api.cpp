@@ -929,8 +929,11 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             const bool fresh = ctx->geo_choice.find(obase.get()) == ctx->geo_choice.end();
             choice = &ctx->geo_choice[obase.get()];
             if (fresh) {   // a decision measured earlier (another context / process) is kept: same plan => same geometry
-                const int saved = ctx->jit->load_choice(obase->cg.source);
-                if (saved >= 0) { choice->chosen = saved; choice->from_cache = true; }
+                // ... unless the two candidates were closer than the box-to-box spread of one binary (+-7 %) when
+                // it was measured: such a decision is measured again once per context, on THIS box
+                double margin = 1.0;
+                const int saved = ctx->jit->load_choice(obase->cg.source, &margin);
+                if (saved >= 0 && margin >= 0.07) { choice->chosen = saved; choice->from_cache = true; }
             }
             // exploring: the candidates alternate, kGeoRuns timed executions each, best time wins
             cand = choice->chosen >= 0 ? choice->chosen : (choice->runs[0] <= choice->runs[1] ? 0 : 1);
@@ -1921,8 +1924,9 @@ int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_
             *out_chosen = it->second.chosen;
             if (out_from_cache) *out_from_cache = it->second.from_cache ? 1 : 0;
         } else {
-            const int saved = ctx->jit->load_choice(plan->cg.source);
-            if (saved >= 0) {
+            double margin = 1.0;
+            const int saved = ctx->jit->load_choice(plan->cg.source, &margin);
+            if (saved >= 0 && margin >= 0.07) {   // (a closer call is measured again by the next execution on this context)
                 *out_chosen = saved;
                 if (out_from_cache) *out_from_cache = 1;
             }

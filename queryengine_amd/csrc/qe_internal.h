@@ -267,7 +267,7 @@ public:
     static std::vector<char> compile(const std::string &source);
     static std::string source_key(const std::string &source);
     // persisted measured decisions (geometry choice) next to the code object; -1 = none
-    int load_choice(const std::string &source) const;
+    int load_choice(const std::string &source, double *margin = nullptr) const;
     void store_choice(const std::string &source, int chosen, const std::string &note) const;
     static int scratch_bytes(const std::vector<char> &code);
     int compiles = 0, disk_hits = 0, mem_hits = 0, last_scratch = -1;

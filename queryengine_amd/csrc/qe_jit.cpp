@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 
@@ -97,11 +98,18 @@ std::string Jit::source_key(const std::string &source) {
 
 // Measured decisions about a plan (which kernel geometry won) are kept next to its code object, so that a new context /
 // a new process runs the same geometry without exploring again.
-int Jit::load_choice(const std::string &source) const {
+int Jit::load_choice(const std::string &source, double *margin) const {
+    if (margin) *margin = 1.0;
     if (cache_dir_.empty()) return -1;
     std::ifstream f(cache_dir_ + "/" + source_key(source) + ".geo");
     int v = -1;
-    if (f && (f >> v) && (v == 0 || v == 1)) return v;
+    if (f && (f >> v) && (v == 0 || v == 1)) {
+        // second line: "default <a> ms, wide <b> ms (...)": how far apart the two candidates were when the choice was made
+        std::string word;
+        double a = 0, b = 0;
+        if (margin && (f >> word >> a >> word >> word >> b) && a > 0 && b > 0) *margin = std::fabs(a - b) / std::min(a, b);
+        return v;
+    }
     return -1;
 }
 
