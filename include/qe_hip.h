@@ -343,11 +343,13 @@ int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_
 int32_t qe_filter_project_conjunct_order(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                          const qe_expr *const *projections, int32_t nproj, int32_t *out_order, int32_t capacity,
                                          int32_t *out_nconj);
-/* Which form the last qe_filter_project on this context ran in (-1: none yet).  The fused executor picks the form from the
+/* Which form the last qe_filter_project / qe_filter_groupby on this context ran in (-1: none yet).  The fused executor picks the form from the
  * share of rows the plan kept last time: the local form up to 3 % (large batches), the LDS-ring single pass below 12 %, the
  * dense single pass from there on. */
 enum { QE_FORM_RING = 0, QE_FORM_TWO_PASS = 1, QE_FORM_DENSE = 2, QE_FORM_PER_NODE = 3, QE_FORM_NO_FILTER = 4,
-       QE_FORM_LOCAL = 5 /* dependency-free scan into per-chunk slots + one move: plans that kept <= 3 % of their rows */ };
+       QE_FORM_LOCAL = 5 /* dependency-free scan into per-chunk slots + one move: plans that kept <= 3 % of their rows */,
+       /* qe_filter_groupby: */ QE_FORM_GROUPBY_DENSE = 8, QE_FORM_GROUPBY_HASHED = 9,
+       QE_FORM_GROUPBY_HASH_PARTITIONED = 10 /* many distinct numeric keys: rows scattered by key hash, an LDS hash table per partition */ };
 int32_t qe_ctx_last_form(const qe_ctx *ctx);
 /* measured device read bandwidth of a plain streaming kernel over nbytes (GB/s): roofline calibration */
 int32_t qe_stream_read_bandwidth(qe_ctx *ctx, int64_t nbytes, int32_t reps, double *out_gbps);

@@ -202,6 +202,8 @@ struct CodegenInput {
     FusedGeometry geo;
     int nontemporal = 1;
     int nt_stores = 1;    // non-temporal stores for the output rows
+    int hp_shift = 0;             // .. buckets per partition = 2^hp_shift (6 .. 11; 0 = 11), fewer when the entry is wide
+    int hp_parts = 0;             // hashed GROUP BY: > 0 = generate the HASH-PARTITIONED form with this many partitions (a power of two, <= 1024)
     std::vector<int> conj_order;  // evaluation order of the filter's conjuncts (a permutation of their written order); empty = as written
     int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
     int prefetch = 1;     // staged filter+project plans: the stage-0 loads of the next sub-tile are issued at the start of this one
@@ -247,6 +249,9 @@ struct CodegenOutput {
     int nparts = 0;
     std::vector<int> val_slot;   // per aggregate: slot of its input value in a record (identical inputs share one)
     int nvals = 0;               // distinct aggregate inputs; a record is 1 + nvals u64 words {header, values}
+    bool hp = false;             // hash-partitioned form of a hashed GROUP BY: dense partitioned passes over {partition, home bucket} pseudo
+                                 // ids, records carry hp_key_words key words from value slot hp_key_slot on, entries = hash_words layout
+    int hp_key_words = 0, hp_key_slot = 0, hp_shift = 11;   // 2^hp_shift buckets per partition
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);
@@ -288,6 +293,8 @@ struct Plan {
     mutable int64_t hash_capacity = 0;        // hashed group-by: entries of the global table that sufficed last time
     mutable int64_t id_capacity = 0;          // .. of the key -> dense id table (qe_ht_build)
     mutable bool use_ids = false;             // .. the keys did not fit the LDS table last time: resolve them to dense ids first
+    mutable int64_t known_keys = -1;          // hashed group-by: groups the last execution produced (picks the hash-partitioned form)
+    mutable bool hp_failed = false;           // .. a partition's LDS table filled up (or the plan does not build): never again
     mutable bool ids_overflow = false;        // .. more than 2^20 - 1 distinct keys: the id build cannot hold them, never try it again
     mutable std::vector<int> conj_order;      // filter+project: evaluation order of the conjuncts chosen from measured pass rates (empty: as written)
     mutable bool conj_decided = false;

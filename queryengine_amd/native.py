@@ -28,6 +28,7 @@ GEN_I64_MOD, GEN_I32_MOD, GEN_F64_UNIT, GEN_F64_MOD, GEN_F64_STEP, GEN_F64_PRICE
 AGG_MIN, AGG_MAX, AGG_SUM, AGG_COUNT, AGG_AVG = range(5)
 COMM_ID_BYTES = 128
 FORM_RING, FORM_TWO_PASS, FORM_DENSE, FORM_PER_NODE, FORM_NO_FILTER, FORM_LOCAL = range(6)
+FORM_GROUPBY_DENSE, FORM_GROUPBY_HASHED, FORM_GROUPBY_HASH_PARTITIONED = 8, 9, 10
 
 
 class QeError(RuntimeError):

@@ -347,7 +347,9 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
                 assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
 
 
-@pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows"])
+@pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows",
+                                  "double_specials_many_hash_partitioned", "int64_many_hash_partitioned", "mixed_keys_hash_partitioned",
+                                  "grows_hash_partitioned"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
@@ -358,7 +360,13 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     from queryengine_amd import engine as E
     rng = np.random.default_rng(77)
     # debug bit 131072 keeps the global-atomic form (the fallback for more than 2^20 keys) instead of dense ids
-    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else [])
+    # debug bit 8388608 forces the hash-partitioned form (round 3: rows scattered by key hash, one LDS hash table per partition)
+    # from the first execution on, with 64 partitions; "grows" (570 k keys) overflows those tables: the execution falls back and
+    # the next one runs with more partitions
+    hp = case.endswith("_hash_partitioned")
+    if hp:
+        case = case[:-len("_hash_partitioned")]
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else [0, 0, 0, 0, 0, 8388608] if hp else [])
     I32 = DataType.INT32
     if case.startswith("double_specials"):
         n = 150_001
@@ -397,16 +405,26 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
     flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
     batch = E.DeviceBatch.from_columns(ctx, cols)
+    forms = []
     for f in (None, flt):
-        for rep in range(2):                                  # the second run starts with the capacity that sufficed
+        for rep in range(3 if hp else 2):                     # the second run starts with the capacity that sufficed
             res = E.filter_groupby(ctx, batch, ctx.compile(f) if f is not None else None,
                                    [ctx.compile(kk) for kk in keys], [ctx.compile(e) for e in exprs], aggs)
             cs = res.to_columns()
             got = [[c.value(i) for c in cs] for i in range(res.count)]
             res.free()
+            forms.append(ctx.last_form)
         want = oracle.filter_groupby(cols, f, keys, exprs, aggs, oracle.BYTECODE_COMPILER)
         assert len(want) > (5 if case != "double_specials" else 9)
         _rows_equal(got, want, len(keys), aggs, oracle)
+    from queryengine_amd import native as N
+    if hp:   # the hash-partitioned form really ran (from the first execution on; "grows" only once its tables are large enough)
+        assert forms[-1] == N.FORM_GROUPBY_HASH_PARTITIONED, forms
+        # (64 partitions hold 131 072 buckets: the 150 000 / 570 000 keys of "int64_many" / "grows" overflow them once, that
+        # execution falls back and reports the key count, the next one sizes its partitions from it)
+        assert case in ("grows", "int64_many") or all(f_ == N.FORM_GROUPBY_HASH_PARTITIONED for f_ in forms), forms
+    else:
+        assert all(f_ == N.FORM_GROUPBY_HASHED for f_ in forms), forms
     batch.free()
     ctx.close()
 
