@@ -250,16 +250,17 @@ def test_group_by_partitioned_sizes_around_tiles_and_chunks(n, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("kind", ["dictionary_100k", "double_100k"])
+@pytest.mark.parametrize("kind", ["dictionary_100k", "double_100k", "double_400k_hash_partitioned"])
 def test_group_by_full_size_properties(kind, oracle):
-    """1 B rows through the partitioned passes (100 000 dictionary keys) and through the dense-id path (100 000 distinct DOUBLE
-    keys): properties that do not need a second engine -- every key is a group, COUNT adds up to the rows the filter keeps (an
+    """1 B rows through the partitioned passes (100 000 dictionary keys), through the dense-id path (100 000 distinct DOUBLE
+    keys) and through the hash-partitioned form (400 000 distinct DOUBLE keys: chosen from the second execution on, once the
+    plan knows how many keys there are): properties that do not need a second engine -- every key is a group, COUNT adds up to the rows the filter keeps (an
     independent filter + COUNT aggregate), SUM adds up to the independent SUM within the reassociation bound, the first
     groups are the keys of the first rows in their order of first appearance (the oracle walks that window row by row)."""
     from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
     from queryengine_amd import engine as E
     from queryengine_amd.workloads import GenColumn
-    n, nkeys = 1_000_000_000, 100_000
+    n, nkeys = 1_000_000_000, (400_000 if kind.startswith("double_400k") else 100_000)
     ctx = E.Context(device=0)
     if kind == "dictionary_100k":
         d = ["k%06d" % i for i in range(nkeys)]
@@ -288,6 +289,8 @@ def test_group_by_full_size_properties(kind, oracle):
         want = oracle.filter_groupby(host, flt, [K], [V, V], [oracle.SUM, oracle.COUNT], oracle.BYTECODE_COMPILER)
         head = [cols[0].value(i) for i in range(len(want))]
         assert head == [w[0] for w in want]
+        if kind.startswith("double_400k"):
+            assert ctx.last_form == (N.FORM_GROUPBY_HASHED if rep == 0 else N.FORM_GROUPBY_HASH_PARTITIONED)
     batch.free()
     ctx.close()
 
