@@ -19,7 +19,13 @@ NOT_A_STEP = re.compile(r"generate_kernel|stream_read|__amd_rocclr")
 
 
 def find(root, pattern):
-    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+    """the files of the NEWEST run only: gpurun merges every run's output into the same scratch directories, and the files
+    of an earlier run of the same case (another process id in the name) must not be counted on top"""
+    files = sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+    if len(files) <= 1:
+        return files
+    newest = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if newest - os.path.getmtime(f) < 120.0]
 
 
 def bench_line(path):
