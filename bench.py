@@ -216,7 +216,7 @@ def main():
     # still plan time: on a fresh JIT cache the first executions of a plan on a large batch time its two kernel geometries
     # (best of 3 each) and persist the choice; do that before the warm-up so that no timed step is an exploring one
     if args.exec_mode == "fused":
-        for _ in range(8):
+        for _ in range(12):
             if E.chosen_geometry(ctx, batch, cf, cp)[0] != -1:
                 break
             r = E.filter_project(ctx, batch, cf, cp)
@@ -335,7 +335,7 @@ def main():
         if args.exec_mode == "fused":   # which of the plan's two kernel geometries the measured choice kept (and whether it came from the JIT cache)
             try:
                 g_, cached_ = E.chosen_geometry(ctx, batch, cf, cp)
-                geometry = {"chosen": {-1: "undecided", 0: "default", 1: "wide"}.get(g_, str(g_)), "from_jit_cache": cached_}
+                geometry = {"chosen": {-1: "undecided", 0: "default", 1: "wide", 2: "mid"}.get(g_, str(g_)), "from_jit_cache": cached_}
             except Exception:
                 geometry = None
         out = {

@@ -328,10 +328,12 @@ int32_t qe_comm_allgather_host(qe_ctx *ctx, const void *send, size_t nbytes, voi
 /* HIP source the JIT would compile for this plan (NUL terminated, owned by ctx, valid until next call) */
 int32_t qe_filter_project_source(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                  const qe_expr *const *projections, int32_t nproj, const char **out);
-/* Which of the fused kernel's two sub-tile geometries this plan runs with on large batches: -1 not decided yet (the first
- * executions on a batch of >= 32 Mi rows time both, best of 3 each), 0 default, 1 wide.  The decision is persisted next
- * to the plan's code object in the JIT cache, so a later context / process runs the same geometry without exploring
- * (*out_from_cache = 1 when it came from there). */
+/* Which of the fused kernel's three geometries this plan runs with on large batches: -1 not decided yet (the first
+ * executions on a batch of >= 32 Mi rows time all three, best of 3 each), 0 default, 1 wide (16 load groups per sub-tile,
+ * 512-entry LDS rings, 2 waves per SIMD), 2 mid (the default sub-tile, 8 Ki-row chunks, 512-entry rings, 2 waves per
+ * workgroup).  The decision is persisted next to the plan's code object in the JIT cache, so a later context / process runs the
+ * same geometry without exploring (*out_from_cache = 1 when it came from there) -- unless the winner was less than 7 % ahead
+ * (the spread of one binary over the boxes of a pool): such a decision is measured again once per context. */
 int32_t qe_filter_project_geometry(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                    const qe_expr *const *projections, int32_t nproj, int32_t *out_chosen,
                                    int32_t *out_from_cache);

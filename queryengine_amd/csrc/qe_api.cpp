@@ -578,7 +578,7 @@ FusedGeometry geometry_of(const qe_ctx *ctx) {
 
 std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,
                                const qe_expr *const *projs, int32_t nproj, const int32_t *agg_fns, bool load,
-                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, bool wide = false, bool dense = false,
+                               const qe_expr *const *keys = nullptr, int32_t nkeys = 0, int geo_cand = 0, bool dense = false,
                                const std::vector<int> *conj_order = nullptr, int hp_parts = 0, int hp_shift = 0) {
     if (nproj < 0 || (nproj > 0 && !projs)) fail(QE_ERR_INVALID_ARG, "bad projection list");
     CodegenInput in;
@@ -600,10 +600,19 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.hp_parts = hp_parts;
     in.hp_shift = hp_shift;
     in.geo = geometry_of(ctx);
+    const bool wide = geo_cand == 1;
     if (wide) {   // the second candidate of the geometry choice (qe_ctx::geo_choice)
         in.geo.unroll = 16;
         in.geo.subs_per_chunk = 4;
         in.geo.ring_entries = 512;
+    } else if (geo_cand == 2) {
+        // the third candidate (round 3): the default sub-tile, 8 Ki-row chunks whose kept rows fit 512-entry rings, two waves per
+        // workgroup.  cfg 2, 1 B rows, three boxes: default / wide / this = 3.56 / 3.29 / 3.19, 3.47 / 3.47 / 3.19 and
+        // (a fast box) 3.35 / 3.13 / 3.20 ms -- which one wins depends on the box, so it is measured like the other two
+        in.geo.unroll = 8;
+        in.geo.subs_per_chunk = 8;
+        in.geo.ring_entries = 512;
+        in.geo.threads = 128;
     }
     in.nontemporal = ctx->opts.tuning[2] % 10 == 2 ? 0 : 1;
     in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
@@ -950,13 +959,20 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
                 if (saved >= 0 && margin >= 0.07) { choice->chosen = saved; choice->from_cache = true; }
             }
             // exploring: the candidates alternate, kGeoRuns timed executions each, best time wins
-            cand = choice->chosen >= 0 ? choice->chosen : (choice->runs[0] <= choice->runs[1] ? 0 : 1);
-            if (cand == 1) {
+            cand = choice->chosen;
+            if (cand < 0) {   // the candidate with the fewest runs so far
+                cand = 0;
+                for (int c = 1; c < qe_ctx::GeoChoice::kCands; c++)
+                    if (choice->runs[c] < choice->runs[cand]) cand = c;
+            }
+            if (cand >= 1) {
                 try {
-                    plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, true, false, order.empty() ? nullptr : &order);
-                } catch (const Error &) {   // the wide candidate does not build for this plan: the default stays
-                    choice->chosen = 0;
+                    plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true, nullptr, 0, cand, false, order.empty() ? nullptr : &order);
+                } catch (const Error &) {   // this candidate does not build for this plan: it is out of the race
+                    choice->runs[cand] = 1 << 20;
+                    if (choice->chosen == cand) choice->chosen = 0;
                     cand = 0;
+                    plan = obase;
                 }
             }
         }
@@ -1228,6 +1244,9 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
         }
         if (nchunks >= (1ll << 31)) fail(QE_ERR_UNSUPPORTED, "batch too large for 32-bit chunk tickets");
         const int grid = (int)std::min<int64_t>((nchunks + waves - 1) / waves, max_grid);
+        static const bool dbg_grid = std::getenv("QE_DEBUG_GRID") != nullptr;
+        if (dbg_grid) std::fprintf(stderr, "[qe] ring kernel: grid %d x %d threads (%d blocks per CU), unroll %d, %d sub-tiles per chunk, ring %d, min_waves %d\n",
+                                   grid, plan->geo.threads, blocks_per_cu(ctx, *plan), plan->geo.unroll, plan->geo.subs_per_chunk, plan->geo.ring_entries, plan->geo.min_waves);
         // scratch: look-back descriptors + one staging slot (chunk_rows rows per output column) per resident wave
         std::vector<void *> scratch;
         struct ScratchGuard {
@@ -1282,12 +1301,17 @@ qe_result *run_fused(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, 
             QE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             choice->best_ms[cand] = std::min(choice->best_ms[cand], ms);
             choice->runs[cand]++;
-            if (choice->runs[0] >= kGeoRuns && choice->runs[1] >= kGeoRuns) {
-                // the wide geometry must win by a margin (2 %): ties go to the default, which holds fewer registers
-                choice->chosen = choice->best_ms[1] < 0.98f * choice->best_ms[0] ? 1 : 0;
-                char note[160];
-                std::snprintf(note, sizeof note, "default %.4f ms, wide %.4f ms (best of %d each, %lld rows)", choice->best_ms[0],
-                              choice->best_ms[1], kGeoRuns, (long long)n);
+            bool all_done = true;
+            for (int c = 0; c < qe_ctx::GeoChoice::kCands; c++) all_done = all_done && choice->runs[c] >= kGeoRuns;
+            if (all_done) {
+                // another geometry must beat the default by a margin (2 %): ties go to the default, which holds fewer registers
+                int best = 0;
+                for (int c = 1; c < qe_ctx::GeoChoice::kCands; c++)
+                    if (choice->best_ms[c] < 0.98f * choice->best_ms[0] && (best == 0 || choice->best_ms[c] < choice->best_ms[best])) best = c;
+                choice->chosen = best;
+                char note[200];
+                std::snprintf(note, sizeof note, "default %.4f ms, wide %.4f ms, mid %.4f ms (best of %d each, %lld rows)", choice->best_ms[0],
+                              choice->best_ms[1], choice->best_ms[2], kGeoRuns, (long long)n);
                 ctx->jit->store_choice(obase->cg.source, choice->chosen, note);
             }
         }
@@ -1987,10 +2011,11 @@ int32_t qe_filter_project_prepare(qe_ctx *ctx, const qe_batch *batch, const qe_e
             // the device never waits for the JIT
             const int k2 = pl->geo.unroll > 0 ? (pl->est_regs - 54) / (2 * pl->geo.unroll) : 99;
             if (!pl->explicit_geometry && pl->est_regs > 0 && 32 * k2 + 54 <= 256 && (ctx->opts.tuning[5] & 8192) == 0)
-                try {
-                    (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, true);
-                } catch (const Error &) {   // optional candidate: the default plan above is what prepare guarantees
-                }
+                for (int c = 1; c < qe_ctx::GeoChoice::kCands; c++)
+                    try {
+                        (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, c);
+                    } catch (const Error &) {   // optional candidates: the default plan above is what prepare guarantees
+                    }
             // the dense single-pass kernel (plans that keep a large share of their rows) is compiled ahead of time as well
             if (filter && (ctx->opts.tuning[5] & 32768) == 0)
                 (void)get_plan(ctx, batch, filter, projections, nproj, nullptr, ctx->device >= 0, nullptr, 0, false, true);

@@ -341,7 +341,13 @@ struct qe_ctx {
     std::map<std::string, std::shared_ptr<qe::Plan>> plans;
     // geometry choice per fused filter+project plan: the first executions on a large batch time the default geometry and
     // the "wide" one (16 load groups per sub-tile, 512-entry LDS rings, 2 waves per SIMD); the faster one is kept
-    struct GeoChoice { int chosen = -1; int runs[2] = {0, 0}; float best_ms[2] = {1e30f, 1e30f}; bool from_cache = false; };
+    struct GeoChoice {
+        static constexpr int kCands = 3;   // 0 default, 1 wide, 2 mid (default sub-tile, 8 Ki-row chunks, 512-entry rings, 2 waves per workgroup)
+        int chosen = -1;
+        int runs[kCands] = {0, 0, 0};
+        float best_ms[kCands] = {1e30f, 1e30f, 1e30f};
+        bool from_cache = false;
+    };
     std::map<const qe::Plan *, GeoChoice> geo_choice;   // plans live as long as the context: the pointer is never recycled
     std::map<int64_t, std::shared_ptr<qe::DictData>> id_dicts;   // placeholder dictionaries of 2^k entries: the domain of a dense-id key column
     std::string source_scratch;

@@ -103,11 +103,16 @@ int Jit::load_choice(const std::string &source, double *margin) const {
     if (cache_dir_.empty()) return -1;
     std::ifstream f(cache_dir_ + "/" + source_key(source) + ".geo");
     int v = -1;
-    if (f && (f >> v) && (v == 0 || v == 1)) {
-        // second line: "default <a> ms, wide <b> ms (...)": how far apart the two candidates were when the choice was made
+    if (f && (f >> v) && v >= 0 && v <= 2) {
+        // second line: "default <a> ms, wide <b> ms, mid <c> ms (...)": how far the winner was ahead of the runner-up
         std::string word;
-        double a = 0, b = 0;
-        if (margin && (f >> word >> a >> word >> word >> b) && a > 0 && b > 0) *margin = std::fabs(a - b) / std::min(a, b);
+        double t[3] = {0, 0, 0};
+        if (margin && (f >> word >> t[0] >> word >> word >> t[1] >> word >> word >> t[2]) && t[0] > 0 && t[1] > 0 && t[2] > 0) {
+            std::sort(t, t + 3);
+            *margin = (t[1] - t[0]) / t[0];
+        } else if (margin) {
+            *margin = 0.0;   // a note of an older layout: measure again
+        }
         return v;
     }
     return -1;

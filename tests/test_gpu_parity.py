@@ -645,11 +645,13 @@ def _workload_vs_oracle(ctx, oracle, wl, n, reps=1):
     batch.free()
 
 
-def test_wide_geometry_parity(oracle):
-    """The second sub-tile geometry of the fused kernel (16 load groups per sub-tile, 512-entry LDS rings, 4 sub-tiles per
-    chunk), pinned through qe_options.tuning: ragged sizes, several chunks, low and high selectivity, dictionary shape."""
+@pytest.mark.parametrize("tuning", [[256, 16, 0, 0, 20004], [128, 8, 0, 0, 20008]], ids=["wide", "mid"])
+def test_wide_geometry_parity(oracle, tuning):
+    """The second and third geometry of the fused kernel (wide: 16 load groups per sub-tile, 512-entry LDS rings, 4 sub-tiles
+    per chunk; mid: the default sub-tile, 8 sub-tiles per chunk, 512-entry rings, 2 waves per workgroup), pinned through
+    qe_options.tuning: ragged sizes, several chunks, low and high selectivity, dictionary shape."""
     from queryengine_amd import workloads as W
-    ctx = E.Context(device=0, tuning=[256, 16, 0, 0, 20004])
+    ctx = E.Context(device=0, tuning=tuning)
     for n in (1, 2047, 2048, 2049, 8191, 8192, 70_001, 300_000):
         _workload_vs_oracle(ctx, oracle, W.config2(n), n)
     for a_limit, c_limit in ((1000, 1.0), (1000, 0.5), (10, 0.5)):
@@ -660,7 +662,7 @@ def test_wide_geometry_parity(oracle):
 
 
 def test_geometry_choice_on_a_large_batch(oracle, tmp_path):
-    """From 32 Mi rows on, the first executions of a plan time the two geometries (best of 3 each) and the faster one is
+    """From 32 Mi rows on, the first executions of a plan time its three geometries (best of 3 each) and the faster one is
     kept: every execution -- exploring or settled -- returns exactly the oracle's rows.  The decision is persisted next to
     the code object: a NEW context on the same JIT cache runs the same geometry without exploring (same plan => same
     geometry) -- unless the two candidates were closer than 7 % (the spread of one binary over the boxes of
@@ -673,11 +675,11 @@ def test_geometry_choice_on_a_large_batch(oracle, tmp_path):
     batch = E.DeviceBatch.describe(ctx, [Column(c.type, np.zeros(2, dtype=np.int64 if c.type == I64 else np.float64)) for c in wl.columns])
     cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in wl.projections]
     assert E.chosen_geometry(ctx, batch, cf, cp) == (-1, False)
-    _workload_vs_oracle(ctx, oracle, wl, n, reps=5)
-    assert E.chosen_geometry(ctx, batch, cf, cp)[0] == -1          # 5 of the 6 exploring executions
+    _workload_vs_oracle(ctx, oracle, wl, n, reps=8)
+    assert E.chosen_geometry(ctx, batch, cf, cp)[0] == -1          # 8 of the 9 exploring executions (three candidates, best of 3)
     _workload_vs_oracle(ctx, oracle, wl, n, reps=2)
     chosen, cached = E.chosen_geometry(ctx, batch, cf, cp)
-    assert chosen in (0, 1) and not cached
+    assert chosen in (0, 1, 2) and not cached
     plain = W.config2(n)
     plain.filter = None                                   # a projection without a Filter takes part in the choice too
     _workload_vs_oracle(ctx, oracle, plain, n, reps=3)
@@ -692,9 +694,9 @@ def test_geometry_choice_on_a_large_batch(oracle, tmp_path):
         assert E.chosen_geometry(ctx2, batch2, cf2, cp2) == (chosen, True)
     else:                                                  # a close call (inside the box-to-box spread): measured again on this context
         assert first == (-1, False)
-        _workload_vs_oracle(ctx2, oracle, wl, n, reps=7)
+        _workload_vs_oracle(ctx2, oracle, wl, n, reps=10)
         again, cached = E.chosen_geometry(ctx2, batch2, cf2, cp2)
-        assert again in (0, 1) and not cached
+        assert again in (0, 1, 2) and not cached
     ctx2.close()
 
 
