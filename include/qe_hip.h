@@ -320,6 +320,13 @@ void qe_comm_destroy(qe_ctx *ctx);             /* also done by qe_ctx_destroy */
  * QE_ERR_INVALID_ARG on EVERY rank (the fingerprints travel in the header all-gather), as is a schema mismatch; a rank that
  * cannot allocate its buffers makes the call fail on every rank before any transfer starts (QE_ERR_OOM). */
 int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result **out);
+/* Collective: Projection(Filter(Scan)) over this rank's shard AND the materialising exchange in one call, OVERLAPPED -- the
+ * shard is scanned in `nslices` slices (<= 16; 0 = 8) and a slice's rows travel to the root (copy stream) while the next slice
+ * is scanned (compute stream).  The root can only place rows at their final offset if every count is known in advance: the
+ * call starts with a count pre-pass (the filter's columns only) and ONE all-gather of every rank's per-slice counts.  Same
+ * result, order and checks as qe_filter_project + qe_gather.  On `root` *out = the whole result, elsewhere NULL. */
+int32_t qe_filter_project_gather(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projections,
+                                 int32_t nproj, int32_t root, int32_t nslices, qe_result **out);
 /* Collective, small control data (aggregate partials, counts): recv gets nranks * nbytes host bytes in rank order.
  * Aggregations over a sharded table fold the per-GPU partials in rank order on the host. */
 int32_t qe_comm_allgather_host(qe_ctx *ctx, const void *send, size_t nbytes, void *recv);

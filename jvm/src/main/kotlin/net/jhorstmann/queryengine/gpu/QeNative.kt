@@ -61,6 +61,8 @@ internal object QeNative {
     val qe_comm_destroy = handle("qe_comm_destroy", null, ADDRESS)
     // collective: ctx, local result, root, qe_result** (non-NULL on root only) -> status (QE_ERR_COMM = 7 on an RCCL failure)
     val qe_gather = handle("qe_gather", JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS)
+    // collective: ctx, batch, filter|NULL, qe_expr*[nproj], nproj, root, nslices (0 = 8), qe_result** -> scan + exchange overlapped
+    val qe_filter_project_gather = handle("qe_filter_project_gather", JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS)
     // collective: ctx, send, nbytes, recv[nranks * nbytes] (host buffers): aggregate partials, counts
     val qe_comm_allgather_host = handle("qe_comm_allgather_host", JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS)
 

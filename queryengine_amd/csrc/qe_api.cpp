@@ -1983,6 +1983,62 @@ qe_result *run_groupby_dense(qe_ctx *ctx, const qe_batch *batch, const std::shar
 
 }  // namespace
 
+// ---- internals of the overlapped scan + exchange (qe_comm.cpp: qe_filter_project_gather) ---------------------------------
+// kept rows of every slice of `slice_rows` rows (a multiple of the plan's chunk) of the batch: ONE launch of the count pass
+// (qe_fp_count: the filter's columns only, late materialisation included) and a 4-byte read-back per chunk
+std::vector<int64_t> qe_int_count_slices(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projs, int32_t nproj,
+                                  int64_t *slice_rows_io, int32_t nslices) {
+    const int64_t n = batch->nrows;
+    auto plan = get_plan(ctx, batch, filter, projs, nproj, nullptr, true);
+    const int64_t chunk_rows = plan->geo.chunk_rows();
+    int64_t slice_rows = (n + nslices - 1) / std::max(1, nslices);
+    slice_rows = std::max<int64_t>(chunk_rows, (slice_rows + chunk_rows - 1) / chunk_rows * chunk_rows);
+    *slice_rows_io = slice_rows;
+    const int64_t ns = n > 0 ? (n + slice_rows - 1) / slice_rows : 0;
+    std::vector<int64_t> counts((size_t)ns, 0);
+    if (n == 0) return counts;
+    if (!filter || !plan->cg.two_pass) {   // no Filter node: every row is kept
+        for (int64_t k = 0; k < ns; k++) counts[(size_t)k] = std::min(slice_rows, n - k * slice_rows);
+        return counts;
+    }
+    const int64_t nchunks = (n + chunk_rows - 1) / chunk_rows;
+    const int waves = plan->geo.threads / 64;
+    hipFunction_t f_count = nullptr;
+    QE_HIP(hipModuleGetFunction(&f_count, plan->kernel.module, "qe_fp_count"));
+    uint32_t *d_counts = (uint32_t *)ctx->pool.alloc((size_t)nchunks * 4);
+    struct G { qe_ctx *c; void *q; ~G() { c->pool.release(q); } } g{ctx, d_counts};
+    FusedParams p;
+    fill_inputs(p, batch, *plan);
+    p.nchunks = nchunks;
+    p.blk = (unsigned long long *)d_counts;
+    void *args[] = {&p};
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + waves - 1) / waves, (int64_t)device_cus(ctx->device) * 8));
+    QE_HIP(hipModuleLaunchKernel(f_count, grid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+    std::vector<uint32_t> h((size_t)nchunks);
+    QE_HIP(hipMemcpyAsync(h.data(), d_counts, (size_t)nchunks * 4, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t per = slice_rows / chunk_rows;
+    for (int64_t c = 0; c < nchunks; c++) counts[(size_t)(c / per)] += h[(size_t)c];
+    return counts;
+}
+
+// Projection(Filter(Scan)) over rows [row_begin, row_begin + nrows) of the batch (row_begin a multiple of 64: bitmap words do
+// not straddle the cut): a view of the batch's columns, no copy
+qe_result *qe_int_run_fused_slice(qe_ctx *ctx, const qe_batch *batch, int64_t row_begin, int64_t nrows, const qe_expr *filter,
+                           const qe_expr *const *projs, int32_t nproj) {
+    if (row_begin % 64 != 0 || row_begin < 0 || nrows < 0 || row_begin + nrows > batch->nrows) fail(QE_ERR_INTERNAL, "bad slice");
+    qe_batch view;
+    view.nrows = nrows;
+    for (const Column &c : batch->cols) {
+        Column v = c;
+        v.owned = false;
+        if (c.data) v.data = (char *)c.data + (c.type == QE_BOOLEAN ? (size_t)(row_begin / 64) * 8 : type_width(c.type) * (size_t)row_begin);
+        if (c.validity) v.validity = c.validity + row_begin / 64;
+        view.cols.push_back(v);
+    }
+    return run_fused(ctx, &view, filter, projs, nproj);
+}
+
 extern "C" {
 
 int32_t qe_filter_project(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter,

@@ -561,4 +561,207 @@ int32_t qe_gather(qe_ctx *ctx, const qe_result *local, int32_t root, qe_result *
     });
 }
 
+constexpr int kGatherMaxSlices = 16;
+
+// Scan + exchange, OVERLAPPED: the shard is scanned in slices and a slice's rows travel to the root while
+// the next slice is scanned.  The root can only place a peer's rows at their final offset if it knows every count in advance,
+// so the call starts with a count pre-pass (the filter's columns only: qe_fp_count) and ONE all-gather of every rank's
+// per-slice counts; after that nothing waits for a count any more:
+//   every rank, slice k:  qe_filter_project on rows [k * S, (k + 1) * S) (compute stream)  ->  transfers of slice k on the COPY
+//   stream (peer: one ncclSend per column buffer; root: one ncclRecv per peer and column at the final offset, bitmap words
+//   through a staging area and bitmap_place; its own slice device-to-device) while slice k + 1 is scanned.
+// Same result as qe_filter_project + qe_gather (rank order, input order), same checks (schema, dictionaries, status word).
+// What it costs and buys at cfg 5 (1.25 B rows per GPU, 7 GB into the root): DESIGN.md 6.
+int32_t qe_filter_project_gather(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projections,
+                                 int32_t nproj, int32_t root, int32_t nslices, qe_result **out) {
+    if (!ctx || !batch || !out || nproj < 0 || (nproj > 0 && !projections)) return QE_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded_comm(ctx, [&] {
+        need_dev(ctx);
+        if (!ctx->comm) fail(QE_ERR_COMM, "qe_filter_project_gather: no communicator (qe_comm_init)");
+        const int nranks = ctx->comm_nranks, rank = ctx->comm_rank;
+        if (root < 0 || root >= nranks) fail(QE_ERR_INVALID_ARG, "qe_filter_project_gather: root out of range");
+        if (nproj > kGatherMaxCols) fail(QE_ERR_UNSUPPORTED, "qe_filter_project_gather: more than 16 columns");
+        if (batch->schema_only) fail(QE_ERR_INVALID_ARG, "schema-only batch (qe_batch_describe) cannot be executed");
+        const int K = std::max(1, std::min(nslices <= 0 ? 8 : nslices, kGatherMaxSlices));
+        RcclApi &nc = rccl();
+        Scratch sc{ctx, {}};
+        // (0) count pre-pass: kept rows of every slice of this shard
+        int64_t slice_rows = 0;
+        std::vector<int64_t> counts = qe_int_count_slices(ctx, batch, filter, projections, nproj, &slice_rows, K);
+        const int ns = (int)counts.size();     // <= K slices really exist (short shards have fewer)
+        // (1) one all-gather: the usual header (shape of this rank's result: taken from a zero-row execution of the plan) + counts
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> probe(qe_int_run_fused_slice(ctx, batch, 0, 0, filter, projections, nproj),
+                                                                            [ctx](qe_result *r) { qe_result_free(ctx, r); });
+        struct SliceHeader {
+            GatherHeader h;
+            int64_t nslices;
+            int64_t count[kGatherMaxSlices];
+        };
+        SliceHeader mine{};
+        mine.h = header_of(probe.get(), true);
+        // a zero-row result carries no validity bitmap: nullability is the plan's (OutColumn::nullable)
+        mine.h.validity_mask = 0;
+        for (size_t c = 0; c < probe->cols.size(); c++)
+            if (probe->cols[c].nullable) mine.h.validity_mask |= 1u << c;
+        mine.nslices = ns;
+        int64_t n_me = 0;
+        for (int k = 0; k < ns; k++) { mine.count[k] = counts[(size_t)k]; n_me += counts[(size_t)k]; }
+        mine.h.count = n_me;
+        std::vector<SliceHeader> hdr((size_t)nranks);
+        {
+            SliceHeader *d_mine = (SliceHeader *)sc.get(sizeof(SliceHeader));
+            SliceHeader *d_all = (SliceHeader *)sc.get(sizeof(SliceHeader) * (size_t)nranks);
+            QE_HIP(hipMemcpyAsync(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+            QE_NCCL(nc.AllGather(d_mine, d_all, sizeof(SliceHeader), kNcclUint8, ctx->comm, ctx->stream));
+            QE_HIP(hipMemcpyAsync(hdr.data(), d_all, sizeof(SliceHeader) * (size_t)nranks, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        int64_t total = 0;
+        uint32_t any_validity = 0;
+        std::vector<int64_t> offset((size_t)nranks, 0);
+        const GatherHeader &ref = hdr[(size_t)root].h;
+        int max_slices = 0;
+        for (int r = 0; r < nranks; r++) {
+            if (hdr[r].h.ncols != ref.ncols || hdr[r].h.type_sig != ref.type_sig)
+                fail(QE_ERR_INVALID_ARG, "qe_filter_project_gather: rank " + std::to_string(r) + " runs a plan of a different result schema than rank " +
+                                             std::to_string(root));
+            for (int c = 0; c < ref.ncols; c++)
+                if (hdr[r].h.dict_fp[c] != ref.dict_fp[c])
+                    fail(QE_ERR_INVALID_ARG, "qe_filter_project_gather: column " + std::to_string(c) + " of rank " + std::to_string(r) +
+                                                 " has another dictionary than on rank " + std::to_string(root));
+            offset[r] = total;
+            total += hdr[r].h.count;
+            any_validity |= hdr[r].h.validity_mask;
+            max_slices = std::max<int>(max_slices, (int)hdr[r].nslices);
+        }
+        const size_t ncols = probe->cols.size();
+        // (2) allocations, then one status word per rank (as qe_gather)
+        std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(nullptr, [ctx](qe_result *r) { free_output(ctx, r); });
+        struct Staged { uint64_t *words; int64_t off, n; uint64_t *dst; };
+        std::vector<std::vector<Staged>> staged((size_t)max_slices);   // root: per slice, in the order the receives are posted
+        int32_t my_status = QE_OK;
+        std::string my_error;
+        const uint64_t *ones = nullptr;   // validity words of a column that is nullable on another rank only
+        try {
+            if ((any_validity & ~mine.h.validity_mask) != 0 && n_me > 0) {
+                uint64_t *w = (uint64_t *)sc.get(words_of(slice_rows) * 8);
+                QE_HIP(hipMemsetAsync(w, 0xff, words_of(slice_rows) * 8, ctx->stream));
+                ones = w;
+            }
+            if (rank == root) {
+                res.reset(make_output(ctx, probe.get(), total, any_validity));
+                for (int k = 0; k < max_slices; k++) {
+                    for (int r = 0; r < nranks; r++) {
+                        if (r == root || k >= hdr[r].nslices || hdr[r].count[k] == 0) continue;
+                        int64_t off = offset[r];
+                        for (int j = 0; j < k; j++) off += hdr[r].count[j];
+                        const int64_t n = hdr[r].count[k];
+                        for (size_t c = 0; c < ncols; c++) {
+                            OutColumn &dst = res->cols[c];
+                            if (dst.type == QE_BOOLEAN) staged[(size_t)k].push_back({(uint64_t *)sc.get(words_of(n) * 8), off, n, (uint64_t *)dst.data});
+                            if (dst.nullable) staged[(size_t)k].push_back({(uint64_t *)sc.get(words_of(n) * 8), off, n, dst.validity});
+                        }
+                    }
+                }
+            }
+        } catch (const Error &e) {
+            my_status = e.code;
+            my_error = e.msg;
+        } catch (const std::bad_alloc &) {
+            my_status = QE_ERR_OOM;
+            my_error = "host out of memory";
+        }
+        {
+            std::vector<int32_t> status((size_t)nranks, 0);
+            int32_t *d_mine = (int32_t *)sc.get(sizeof(int32_t));
+            int32_t *d_all = (int32_t *)sc.get(sizeof(int32_t) * (size_t)nranks);
+            QE_HIP(hipMemcpyAsync(d_mine, &my_status, sizeof my_status, hipMemcpyHostToDevice, ctx->stream));
+            QE_NCCL(nc.AllGather(d_mine, d_all, sizeof(int32_t), kNcclUint8, ctx->comm, ctx->stream));
+            QE_HIP(hipMemcpyAsync(status.data(), d_all, sizeof(int32_t) * (size_t)nranks, hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            if (my_status != QE_OK) fail(my_status, "qe_filter_project_gather: " + my_error);
+            for (int r = 0; r < nranks; r++)
+                if (status[r] != QE_OK)
+                    fail(status[r], "qe_filter_project_gather: rank " + std::to_string(r) + " could not allocate its buffers; the exchange was not started");
+        }
+        // (3) slices: scan on the compute stream, transfers on the copy stream
+        std::vector<std::unique_ptr<qe_result, std::function<void(qe_result *)>>> parts;   // alive until their transfers have completed
+        struct Drain {   // whatever happens, nothing in flight may outlive the buffers it reads or writes
+            qe_ctx *c;
+            ~Drain() { (void)hipStreamSynchronize(c->copy_stream); }
+        } drain{ctx};
+        int64_t my_off = offset[(size_t)rank];
+        for (int k = 0; k < max_slices; k++) {
+            qe_result *part = nullptr;
+            int64_t n_k = 0;
+            if (k < ns) {
+                const int64_t b = (int64_t)k * slice_rows, e = std::min<int64_t>(batch->nrows, b + slice_rows);
+                part = qe_int_run_fused_slice(ctx, batch, b, e - b, filter, projections, nproj);   // returns when the slice is complete
+                parts.emplace_back(part, [ctx](qe_result *r) { qe_result_free(ctx, r); });
+                n_k = part->count;
+                if (n_k != counts[(size_t)k])
+                    fail(QE_ERR_INTERNAL, "qe_filter_project_gather: slice " + std::to_string(k) + " kept " + std::to_string(n_k) + " rows, the count pass said " +
+                                              std::to_string(counts[(size_t)k]));
+            }
+            if (rank != root) {
+                if (n_k > 0) {
+                    RcclGroup group(nc);
+                    for (size_t c = 0; c < ncols; c++) {
+                        const OutColumn &src = part->cols[c];
+                        const size_t nb = src.type == QE_BOOLEAN ? words_of(n_k) * 8 : width_of(src.type) * (size_t)n_k;
+                        QE_NCCL(nc.Send(src.data, nb, kNcclUint8, root, ctx->comm, ctx->copy_stream));
+                        if ((any_validity >> c) & 1u)
+                            QE_NCCL(nc.Send(src.validity ? src.validity : ones, words_of(n_k) * 8, kNcclUint8, root, ctx->comm, ctx->copy_stream));
+                    }
+                    group.end();
+                }
+                continue;
+            }
+            // root: this slice of every peer, then its own
+            {
+                bool any = false;
+                for (int r = 0; r < nranks; r++) any = any || (r != root && k < hdr[r].nslices && hdr[r].count[k] > 0);
+                if (any) {
+                    RcclGroup group(nc);
+                    size_t si = 0;
+                    for (int r = 0; r < nranks; r++) {
+                        if (r == root || k >= hdr[r].nslices || hdr[r].count[k] == 0) continue;
+                        int64_t off = offset[r];
+                        for (int j = 0; j < k; j++) off += hdr[r].count[j];
+                        const int64_t n = hdr[r].count[k];
+                        for (size_t c = 0; c < ncols; c++) {
+                            OutColumn &dst = res->cols[c];
+                            if (dst.type == QE_BOOLEAN)
+                                QE_NCCL(nc.Recv(staged[(size_t)k][si++].words, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->copy_stream));
+                            else
+                                QE_NCCL(nc.Recv((char *)dst.data + width_of(dst.type) * (size_t)off, width_of(dst.type) * (size_t)n, kNcclUint8, r,
+                                                ctx->comm, ctx->copy_stream));
+                            if (dst.nullable) QE_NCCL(nc.Recv(staged[(size_t)k][si++].words, words_of(n) * 8, kNcclUint8, r, ctx->comm, ctx->copy_stream));
+                        }
+                    }
+                    group.end();
+                }
+                for (const Staged &s_ : staged[(size_t)k]) launch_bitmap_place(ctx->copy_stream, s_.dst, s_.off, s_.words, s_.n);
+            }
+            if (n_k > 0) {
+                for (size_t c = 0; c < ncols; c++) {
+                    const OutColumn &src = part->cols[c];
+                    OutColumn &dst = res->cols[c];
+                    if (src.type == QE_BOOLEAN)
+                        launch_bitmap_place(ctx->copy_stream, (uint64_t *)dst.data, my_off, (const uint64_t *)src.data, n_k);
+                    else
+                        QE_HIP(hipMemcpyAsync((char *)dst.data + width_of(src.type) * (size_t)my_off, src.data, width_of(src.type) * (size_t)n_k,
+                                              hipMemcpyDeviceToDevice, ctx->copy_stream));
+                    if (dst.nullable) launch_bitmap_place(ctx->copy_stream, dst.validity, my_off, src.validity ? src.validity : ones, n_k);
+                }
+                my_off += n_k;
+            }
+        }
+        QE_HIP(hipGetLastError());
+        QE_HIP(hipStreamSynchronize(ctx->copy_stream));
+        if (rank == root) *out = res.release();
+    });
+}
+
 }  // extern "C"

@@ -384,3 +384,9 @@ struct qe_host_result {
     hipEvent_t done = nullptr;
     bool waited = false;
 };
+
+// internals shared by qe_api.cpp and qe_comm.cpp (the overlapped scan + exchange)
+std::vector<int64_t> qe_int_count_slices(qe_ctx *ctx, const qe_batch *batch, const qe_expr *filter, const qe_expr *const *projs, int32_t nproj,
+                                         int64_t *slice_rows_io, int32_t nslices);
+qe_result *qe_int_run_fused_slice(qe_ctx *ctx, const qe_batch *batch, int64_t row_begin, int64_t nrows, const qe_expr *filter,
+                                  const qe_expr *const *projs, int32_t nproj);

@@ -355,3 +355,30 @@ def time_gather(ctx, batch, cf, cp, world: int, rank: int, reps: int = 3):
             "gbps_into_root": (nbytes / best / 1e9) if best else None,
             "method": "qe_gather (C ABI, RCCL direct): ncclAllGather of result headers + one ncclGroupStart/End of "
                       "ncclRecv at final offsets / ncclSend per column (direct peer links), rank order, bitmap words"}
+
+
+def time_gather_overlapped(ctx, batch, cf, cp, world: int, rank: int, nslices: int = 8, reps: int = 3):
+    """bench.py: the scan and the exchange in ONE overlapped call (qe_filter_project_gather: count pre-pass, the shard scanned
+    in slices, every slice's rows on their way to the root while the next slice is scanned), to be read against
+    time_gather's scan_plus_gather_ms."""
+    import torch.distributed as dist
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    best, rows_on_root = None, 0
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        g = ctx.filter_project_gather(batch, cf, cp, 0, nslices)
+        barrier()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        if g is not None:
+            rows_on_root = g.count
+            g.free()
+    return {"ms": best * 1e3, "rows_on_root": rows_on_root, "slices": nslices,
+            "method": "qe_filter_project_gather (C ABI): count pre-pass + one all-gather of per-slice counts, then per slice the scan "
+                      "(compute stream) and grouped ncclSend / ncclRecv at final offsets (copy stream)"}

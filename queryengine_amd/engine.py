@@ -126,6 +126,15 @@ class Context:
         N.check(self.handle, self._lib.qe_gather(self.handle, result.handle, root, C.byref(h)))
         return Result(self, h) if h.value else None
 
+    def filter_project_gather(self, batch: "DeviceBatch", filter: Optional["CompiledExpression"], projections: Sequence["CompiledExpression"],
+                              root: int = 0, nslices: int = 0) -> Optional["Result"]:
+        """qe_filter_project_gather (collective): scan of this rank's shard in slices with every slice's rows travelling to
+        `root` while the next slice is scanned; the whole result on `root`, None elsewhere."""
+        h = C.c_void_p()
+        N.check(self.handle, self._lib.qe_filter_project_gather(self.handle, batch.handle, filter.handle if filter else None,
+                                                                _expr_array(projections), len(projections), root, nslices, C.byref(h)))
+        return Result(self, h) if h.value else None
+
     def allgather_host(self, payload: bytes) -> List[bytes]:
         """qe_comm_allgather_host (collective): every rank's `payload` (equal sizes), in rank order."""
         n = self.comm_nranks

@@ -121,6 +121,7 @@ SYMBOLS = [
     ("qe_comm_nranks", C.c_int32, [_P]),
     ("qe_comm_destroy", None, [_P]),
     ("qe_gather", C.c_int32, [_P, _P, C.c_int32, C.POINTER(_P)]),
+    ("qe_filter_project_gather", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("qe_comm_allgather_host", C.c_int32, [_P, _P, C.c_size_t, _P]),
     ("qe_filter_project_source", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_char_p)]),
     ("qe_filter_project_geometry", C.c_int32, [_P, _P, _P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

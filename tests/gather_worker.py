@@ -89,6 +89,57 @@ def main():
         n = 200_000
         cfg2_case("cfg2_shard_range_root0", [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)], 0)
 
+        # ---- the OVERLAPPED form: scan in slices, every slice's rows on their way while the next one is scanned ----
+        def overlapped_case(name, sizes, root, nslices):
+            wl = W.config2(sum(sizes), null_pct=1)
+            projs = list(wl.projections) + [fn(Fn.CMP_LT, col("c", 2, D), num(0.25)), fn(Fn.CMP_GT, col("b", 1, I64), num(7))]
+            cf, cp = ctx.compile(wl.filter), [ctx.compile(p) for p in projs]
+            begin = sum(sizes[:rank])
+            batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], sizes[rank], row_begin=begin)
+            g = ctx.filter_project_gather(batch, cf, cp, root, nslices)
+            if rank == root:
+                whole_b = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], sum(sizes), row_begin=0)
+                whole = E.filter_project(ctx, whole_b, cf, cp)
+                ok, detail = compare(g, whole, name)
+                note(name, ok, detail)
+                whole.free(); whole_b.free(); g.free()
+            else:
+                note(name, g is None)
+            batch.free()
+        # several 16 Ki-row chunks per slice, ragged tails, ranks with different numbers of slices, an empty shard
+        big = [64 * 5000 + 17, 64 * 900, 64 * 3000 + 5][:world] if world >= 3 else [64 * 5000 + 17, 64 * 900]
+        overlapped_case("overlapped_gather_ragged_root0", big, 0, 4)
+        overlapped_case("overlapped_gather_root_last_16_slices", big, world - 1, 16)
+        overlapped_case("overlapped_gather_empty_shard", [64 * 2000, 0, 64 * 700 + 9][:world] if world >= 3 else [0, 64 * 700 + 9], 1 % world, 3)
+
+        # no Filter node: every row travels (BOOLEAN values as bitmap words across slice boundaries that are not multiples of 64 kept rows)
+        def overlapped_no_filter():
+            k = 40_000 + 1000 * rank
+            base = 1_000_000 * rank
+            data = np.arange(base, base + k, dtype=np.float64)
+            valid = (np.arange(k) % 5 != 0) if rank % 2 == 0 else None
+            b = E.DeviceBatch.from_columns(ctx, [Column(DataType.DOUBLE, data, valid)])
+            projs = [col("x", 0, D), fn(Fn.CMP_LT, col("x", 0, D), num(base + 20_000))]
+            g = ctx.filter_project_gather(b, None, [ctx.compile(p) for p in projs], 0, 2)
+            if rank == 0:
+                want_d, want_v, want_b = [], [], []
+                for r in range(world):
+                    kr = 40_000 + 1000 * r
+                    d_ = np.arange(1_000_000 * r, 1_000_000 * r + kr, dtype=np.float64)
+                    want_d.append(d_)
+                    want_v.append((np.arange(kr) % 5 != 0) if r % 2 == 0 else np.ones(kr, bool))
+                    want_b.append(d_ < 1_000_000 * r + 20_000)
+                want_d, want_v, want_b = np.concatenate(want_d), np.concatenate(want_v), np.concatenate(want_b)
+                got = g.to_columns()
+                ok = np.array_equal(got[0].valid, want_v) and np.array_equal(got[0].data[want_v], want_d[want_v])
+                ok = ok and np.array_equal(got[1].valid, want_v) and np.array_equal(got[1].data[want_v], want_b[want_v])
+                note("overlapped_gather_no_filter_mixed_validity", ok, f"{g.count} rows")
+                g.free()
+            else:
+                note("overlapped_gather_no_filter_mixed_validity", g is None)
+            b.free()
+        overlapped_no_filter()
+
         # ---- a shard WITHOUT a validity bitmap next to shards with one (the missing bitmap counts as ones) ----
         def mixed_validity(root):
             k = 1000 + 37 * rank

@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRANSPORT = os.path.join(ROOT, "tests", "transport", "libqe_test_transport.so")
 
-EXPECTED = ["comm_init", "allgather_host", "cfg2_nullable_ragged_empty_shard_root1", "cfg2_shard_range_root0", "mixed_validity",
+EXPECTED = ["comm_init", "allgather_host", "cfg2_nullable_ragged_empty_shard_root1", "cfg2_shard_range_root0",
+            "overlapped_gather_ragged_root0", "overlapped_gather_root_last_16_slices", "overlapped_gather_empty_shard",
+            "overlapped_gather_no_filter_mixed_validity", "mixed_validity",
             "shared_dictionary", "dictionary_mismatch_is_invalid_arg_on_every_rank", "schema_mismatch_is_invalid_arg_on_every_rank",
             "gather_after_errors", "root_out_of_range", "done"]
 
@@ -93,3 +95,6 @@ def test_bench_rehearsal_two_ranks_runs_the_exchange(native_lib):
     assert "error" not in g, g
     assert g["rows_on_root"] == out["config"]["selected_rows_total"] and abs(g["rows_on_root"] / 80e6 - 0.05) < 0.001
     assert g["ms"] > 0 and g["scan_plus_gather_ms"] >= g["ms"] * 0.5
+    ov = g["overlapped"]
+    assert "error" not in ov, ov
+    assert ov["rows_on_root"] == g["rows_on_root"] and ov["ms"] > 0
