@@ -615,6 +615,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         in.geo.threads = 128;
     }
     in.nontemporal = ctx->opts.tuning[2] % 10 == 2 ? 0 : 1;
+    in.vec_stores = ctx->opts.tuning[2] % 10 == 5 ? 1 : 0;   // tuning[2] % 10 == 5: 16-byte output stores (measurement)
     in.nt_stores = ctx->opts.tuning[2] % 10 == 3 ? 0 : ctx->opts.tuning[2] % 10 == 4 ? 2 : 1;   // tuning[2] % 10: 2 plain loads, 3 plain output stores, 4 nt spill stores too
     in.debug_mask = ctx->opts.tuning[5] & 255;   // bits 256.. are host-side switches, not ablation builds
     in.staged = (ctx->opts.tuning[5] & 2048) == 0;
@@ -633,7 +634,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.filter_load_stages = (ctx->opts.tuning[5] & 4096) ? 1 : 0;   // bit 4096: every filter column in the first load stage   // bit 2048: load every column for every row (no late materialisation)
     std::ostringstream key;
     key << "m" << (agg_fns ? 1 : 0) << (in.dense ? "D" : "") << "c" << in.cmp_semantics << "t" << in.geo.threads << "u" << in.geo.unroll << "s"
-        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << "L" << (in.staged ? 1 : 0) << "P" << in.prefetch << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
+        << in.geo.subs_per_chunk << "n" << in.nontemporal << in.nt_stores << in.vec_stores << "L" << (in.staged ? 1 : 0) << "P" << in.prefetch << "." << in.filter_load_stages << "k" << in.geo.lookback_k << "G" << in.geo.gate_period_log2 << "." << in.geo.gate_width_log2 << "d" << in.debug_mask << "r" << in.geo.resolve_at << "g" << in.geo.stagger << "w" << in.geo.min_waves << "p" << in.geo.prio_mode << "b" << in.geo.nbuf << "R" << in.geo.ring_entries << "|";
     for (const Column &c : batch->cols) {
         in.schema.push_back(BoundColumn{c.type, c.validity != nullptr, c.dict});
         key << c.type << (c.validity ? 'n' : 'v') << (c.dict ? c.dict->id : 0) << ",";   // the dictionary's serial number, not its address

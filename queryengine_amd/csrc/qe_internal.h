@@ -201,6 +201,7 @@ struct CodegenInput {
     int cmp_semantics = QE_CMP_TOTAL_ORDER;
     FusedGeometry geo;
     int nontemporal = 1;
+    int vec_stores = 0;   // the ring kernel moves a resolved chunk's rows two per lane (16-byte stores for 8-byte columns)
     int nt_stores = 1;    // non-temporal stores for the output rows
     int hp_shift = 0;             // .. buckets per partition = 2^hp_shift (6 .. 11; 0 = 11), fewer when the entry is wide
     int hp_parts = 0;             // hashed GROUP BY: > 0 = generate the HASH-PARTITIONED form with this many partitions (a power of two, <= 1024)

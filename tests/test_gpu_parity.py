@@ -754,6 +754,24 @@ def test_conjuncts_are_ordered_by_measured_pass_rate(oracle):
         assert_columns_equal(g, w, "written vs swapped")
 
 
+def test_two_rows_per_lane_output_stores(oracle):
+    """Measurement switch tuning[2] % 10 == 5: a resolved chunk's rows leave the LDS ring two per lane (16-byte stores for
+    8-byte columns, one row peeled when the chunk's first position is odd).  Same rows as the oracle around the sub-tile and
+    chunk boundaries, odd / even chunk counts, nullable outputs and a 4-byte output column."""
+    from queryengine_amd import workloads as W
+    ctx = E.Context(device=0, tuning=[0, 0, 5, 0, 0, 1024 | 524288 | 32768, 0, 0])
+    for n in (1, 2, 3, 1023, 1025, 16384, 16385, 40_001, 300_007):
+        for null_pct in (0, 3):
+            wl = W.config2(n, a_limit=300, null_pct=null_pct)
+            batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in wl.columns], n, row_begin=777 * 64)
+            cols = [batch.column_to_host(j) for j in range(batch.ncols)]
+            batch.free()
+            projs = list(wl.projections) + [fn(Fn.CMP_LT, col("c", 2, D), num(0.25))]
+            run_both(ctx, oracle, cols, wl.filter, projs)
+    assert ctx.last_form == N.FORM_RING
+    ctx.close()
+
+
 @pytest.mark.parametrize("bits", [4194304, 4194304 | 262144, 2097152])
 def test_stage0_prefetch_forced_and_off(oracle, bits):
     """Staged plans issue the stage-0 loads of the NEXT sub-tile at the start of the current one (by default only plans with
