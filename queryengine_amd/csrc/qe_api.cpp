@@ -1732,7 +1732,22 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
         const int rec_words = 1 + cg.nvals;
         p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);
         const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * (plan->geo.threads >= 512 ? 1 : kScatterWgsPerCu)));
+        hipDeviceptr_t dbg = nullptr;
+        size_t dbg_bytes = 0;
+        if (ctx->opts.tuning[5] & 64) {
+            QE_HIP(hipModuleGetGlobal(&dbg, &dbg_bytes, plan->kernel.module, "qe_dbg"));
+            QE_HIP(hipMemsetAsync(dbg, 0, dbg_bytes, ctx->stream));
+        }
         QE_HIP(hipModuleLaunchKernel(f_scatter, sgrid, 1, 1, plan->geo.threads, 1, 1, 0, ctx->stream, args, nullptr));
+        if (dbg) {   // diagnostic build: shader clocks per phase, summed over the waves
+            unsigned long long h[8] = {};
+            QE_HIP(hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            QE_HIP(hipStreamSynchronize(ctx->stream));
+            const double waves_total = (double)sgrid * waves;
+            std::fprintf(stderr, "qe_gb_scatter (hash-partitioned) phases, clocks per wave (grid %d x %d waves): issue loads %.0f | flush (stores) %.0f | "
+                         "LDS sort %.0f | wait loads + evaluate %.0f | chunk drain %.0f\n", sgrid, waves, h[0] / waves_total,
+                         h[1] / waves_total, h[2] / waves_total, h[3] / waves_total, h[4] / waves_total);
+        }
         const int64_t cap = (int64_t)P * cg.part_groups;   // every bucket of every partition: cannot be exceeded
         unsigned long long *d_out = (unsigned long long *)talloc((size_t)cap * HW * 8);
         p.agg_partial = (double *)d_out;
@@ -2220,23 +2235,26 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         if (cg.hashed) {
             // many distinct keys (known from an earlier execution of this plan): the hash-partitioned form -- every pass
             // streams -- instead of the id build + dense passes (100 000 DOUBLE keys, 1 B rows: 24 ms that way)
-            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 22.3 ms,
-            // 100 000 keys 24.0 / 25.1, 300 000 keys 32.1 / 23.5, 1 000 000 keys 57 / 47 -- it pays from a few hundred thousand keys on
-            static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 200000;
+            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 19.3 ms,
+            // 100 000 keys 24.0 / 18.9 - 20.3, 300 000 keys 32.1 / 21.9, 1 000 000 keys 57 / 47 -- it pays from a few ten thousand keys on
+            static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 25000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;
             if (!hp_never && !plan->hp_failed && n > 0 && n < (1ll << 32) && nkeys <= 4 && nagg <= 8 &&
                 (hp_forced || (plan->known_keys >= hp_from && n >= (4ll << 20)))) {
-                // ONE workgroup aggregates a partition, so there are at least two partitions per CU (128 partitions left half the
-                // chip idle: 21.8 ms for the aggregation of 1 B records); buckets for ~2.5x the keys seen, 256 .. 2048 per partition
-                // (a small table lets two workgroups share a CU)
+                // ONE workgroup aggregates a partition (128 partitions left half the chip idle: 21.8 ms for the aggregation of 1 B
+                // records).  Fewer partitions make longer runs per scatter tile -- less padding to whole lines --, more partitions keep
+                // the tables sparse: 256 up to ~130 000 keys, 512 up to ~400 000, 1024 beyond.  Buckets for ~5x the keys seen, 256 ..
+                // 2048 per partition: a wave leaves the probe loop after its LONGEST probe sequence, so the tables are kept sparse
+                // (100 000 keys, 1 B rows: 512 partitions x 512 / 1024 / 2048 buckets 28.8 / 22.1 / 21.0 ms, 256 x 2048 20.3 ms)
                 static const int env_parts = std::getenv("QE_HP_PARTS") ? std::atoi(std::getenv("QE_HP_PARTS")) : 0;
                 static const int env_shift = std::getenv("QE_HP_SHIFT") ? std::atoi(std::getenv("QE_HP_SHIFT")) : 0;
+                static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 5;
                 const int64_t keys_seen = std::max<int64_t>(plan->known_keys, 1);
-                int P = hp_forced && plan->known_keys <= 0 ? 64 : keys_seen * 5 / 2 > 512ll * 2048 ? 1024 : 512;
+                int P = hp_forced && plan->known_keys <= 0 ? 64 : keys_seen > 400000 ? 1024 : keys_seen > 130000 ? 512 : 256;
                 if (env_parts >= 2) P = env_parts;
                 int shift = 8;
-                while (shift < 11 && ((int64_t)P << shift) < keys_seen * 5 / 2) shift++;
+                while (shift < 11 && ((int64_t)P << shift) < keys_seen * env_fill) shift++;
                 if (env_shift >= 6) shift = env_shift;
                 std::shared_ptr<Plan> hplan;
                 try {
