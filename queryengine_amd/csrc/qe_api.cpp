@@ -598,6 +598,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.cmp_semantics = ctx->opts.cmp_semantics;
     if (conj_order) in.conj_order = *conj_order;
     in.hp_parts = hp_parts;
+    // records in 128-byte lines pad in units of 6 / 4 / 3 / 2 where {header, words} records of 32 bytes pad in units of 4: they win
+    // while a scatter tile holds long runs per partition (1 B rows, SELECT k, MIN(v), MAX(v), lines / records: 256 partitions, 30 000
+    // keys 17.0 / 19.5 ms, 100 000 keys 18.2 / 19.1; 512 partitions, 300 000 keys 24.9 / 23.0; 1024 partitions, 1 M keys 51.9 / 45.5).
+    // Debug bit 33554432: always {header, words} records.
+    in.hp_lines = (ctx->opts.tuning[5] & 33554432) == 0 && hp_parts <= 256 ? 1 : 0;
     in.hp_shift = hp_shift;
     in.geo = geometry_of(ctx);
     const bool wide = geo_cand == 1;
@@ -651,7 +656,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     }
     if (agg_fns)
         for (int a : in.agg_fns) key << "|a" << a;
-    if (in.hp_parts) key << "|H" << in.hp_parts << "." << in.hp_shift;
+    if (in.hp_parts) key << "|H" << in.hp_parts << "." << in.hp_shift << "." << in.hp_lines;
     if (!in.conj_order.empty()) {
         key << "|O";
         for (int o : in.conj_order) key << o << ".";
@@ -690,7 +695,16 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         const size_t rec = (size_t)(1 + plan->cg.nvals) * 8;
         in.geo.threads = 512;
         int u = 4;
-        while (u > 1 && (size_t)(in.geo.threads / 64) * 128 * u * rec > 128 * 1024) u /= 2;
+        if (plan->cg.hp_line_recs) {   // the stage holds the tile's LINES: every partition's run padded to whole lines, in the worst case
+            const size_t R = (size_t)plan->cg.hp_line_recs, P = (size_t)plan->cg.nparts;
+            auto lds = [&](int uu) {
+                const size_t tile = (size_t)(in.geo.threads / 64) * 128 * uu, lines = (tile + (R - 1) * P + R - 1) / R;
+                return lines * 132 + ((P + 3) & ~(size_t)3) * 16 + 64;
+            };
+            while (u > 1 && lds(u) > 156 * 1024) u /= 2;
+        } else {
+            while (u > 1 && (size_t)(in.geo.threads / 64) * 128 * u * rec > 128 * 1024) u /= 2;
+        }
         in.geo.unroll = u;
         plan->cg = generate_fused_source(in);
     }
@@ -1730,7 +1744,8 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
     if (m_records > 0) {
         p.l1 = d_start;
         const int rec_words = 1 + cg.nvals;
-        p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);
+        if (cg.hp_line_recs) p.desc = (unsigned long long *)talloc((size_t)(m_records / cg.hp_line_recs + 2) * 128);   // whole lines + the spare line
+        else p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);
         const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * (plan->geo.threads >= 512 ? 1 : kScatterWgsPerCu)));
         hipDeviceptr_t dbg = nullptr;
         size_t dbg_bytes = 0;
@@ -2235,8 +2250,8 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         if (cg.hashed) {
             // many distinct keys (known from an earlier execution of this plan): the hash-partitioned form -- every pass
             // streams -- instead of the id build + dense passes (100 000 DOUBLE keys, 1 B rows: 24 ms that way)
-            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 19.3 ms,
-            // 100 000 keys 24.0 / 18.9 - 20.3, 300 000 keys 32.1 / 21.9, 1 000 000 keys 57 / 47 -- it pays from a few ten thousand keys on
+            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 17.0 ms,
+            // 100 000 keys 24.0 / 18.2, 300 000 keys 32.1 / 23.0, 1 000 000 keys 57 / 45.5 -- it pays from a few ten thousand keys on
             static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 25000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;

@@ -204,6 +204,7 @@ struct CodegenInput {
     int vec_stores = 0;   // the ring kernel moves a resolved chunk's rows two per lane (16-byte stores for 8-byte columns)
     int nt_stores = 1;    // non-temporal stores for the output rows
     int hp_shift = 0;             // .. buckets per partition = 2^hp_shift (6 .. 11; 0 = 11), fewer when the entry is wide
+    int hp_lines = 1;             // .. 0: records {header, values, key words} padded to a power of two instead of lines of records (measurement)
     int hp_parts = 0;             // hashed GROUP BY: > 0 = generate the HASH-PARTITIONED form with this many partitions (a power of two, <= 1024)
     std::vector<int> conj_order;  // evaluation order of the filter's conjuncts (a permutation of their written order); empty = as written
     int filter_load_stages = 0;   // > 0: at most this many load stages for the filter's columns (later conjuncts' columns join the last one)
@@ -253,6 +254,7 @@ struct CodegenOutput {
     bool hp = false;             // hash-partitioned form of a hashed GROUP BY: dense partitioned passes over {partition, home bucket} pseudo
                                  // ids, records carry hp_key_words key words from value slot hp_key_slot on, entries = hash_words layout
     int hp_key_words = 0, hp_key_slot = 0, hp_shift = 11;   // 2^hp_shift buckets per partition
+    int hp_line_recs = 0;        // .. > 0: records live in 128-byte lines {R x value / key words, R x 32-bit row id, R x flag byte}; R = this
 };
 
 CodegenOutput generate_fused_source(const CodegenInput &in);

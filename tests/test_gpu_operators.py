@@ -352,7 +352,7 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
 
 @pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows",
                                   "double_specials_many_hash_partitioned", "int64_many_hash_partitioned", "mixed_keys_hash_partitioned",
-                                  "grows_hash_partitioned"])
+                                  "grows_hash_partitioned", "int64_many_hash_partitioned_records", "grows_hash_partitioned_records"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
@@ -366,10 +366,16 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     # debug bit 8388608 forces the hash-partitioned form (round 3: rows scattered by key hash, one LDS hash table per partition)
     # from the first execution on, with 64 partitions; "grows" (570 k keys) overflows those tables: the execution falls back and
     # the next one runs with more partitions
+    # its records live in 128-byte lines of R records {value / key words, row ids, flag bytes}: R = 3 / 4 / 2 for the 4 / 3 / 6 words of
+    # these cases; "_records" (debug bit 33554432) keeps the first layout, one {header, words} record padded to a power of two
+    records = case.endswith("_records")
+    if records:
+        case = case[:-len("_records")]
     hp = case.endswith("_hash_partitioned")
     if hp:
         case = case[:-len("_hash_partitioned")]
-    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else [0, 0, 0, 0, 0, 8388608] if hp else [])
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 131072] if case.endswith("global_atomics") else
+                    [0, 0, 0, 0, 0, 8388608 | (33554432 if records else 0)] if hp else [])
     I32 = DataType.INT32
     if case.startswith("double_specials"):
         n = 150_001
