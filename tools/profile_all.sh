@@ -24,7 +24,8 @@ CASES[cfg4]="bench.py --workload config4"
 CASES[cfg2_pernode]="bench.py --workload config2 --exec-mode per_node"
 CASES[q6agg]="tools/bench_q6.py"
 CASES[groupby]="tools/bench_groupby.py 1000000000 1000,100000,1000000"
-ORDER="cfg2 cfg2_null cfg2_swapped cfg2_sel001 cfg2_sel010 cfg2_sel050 cfg2_sel100 cfg3 cfg4 cfg2_pernode q6agg groupby"
+CASES[groupby_numeric]="tools/bench_groupby_numeric.py 1000000000 100000,300000"
+ORDER="cfg2 cfg2_null cfg2_swapped cfg2_sel001 cfg2_sel010 cfg2_sel050 cfg2_sel100 cfg3 cfg4 cfg2_pernode q6agg groupby groupby_numeric"
 [ $# -gt 0 ] && ORDER="$*"
 cd /tmp
 for C in $ORDER; do
