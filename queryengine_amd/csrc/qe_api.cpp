@@ -600,7 +600,7 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     in.hp_parts = hp_parts;
     // records in 128-byte lines pad in units of 6 / 4 / 3 / 2 where {header, words} records of 32 bytes pad in units of 4: they win
     // while a scatter tile holds long runs per partition (1 B rows, SELECT k, MIN(v), MAX(v), lines / records: 256 partitions, 30 000
-    // keys 17.0 / 19.5 ms, 100 000 keys 18.2 / 19.1; 512 partitions, 300 000 keys 24.9 / 23.0; 1024 partitions, 1 M keys 51.9 / 45.5).
+    // keys 17.0 / 19.5 ms, 100 000 keys 17.4 / 19.9; 512 partitions, 300 000 keys 24.9 / 23.0; 1024 partitions, 1 M keys 51.9 / 45.5).
     // Debug bit 33554432: always {header, words} records.
     in.hp_lines = (ctx->opts.tuning[5] & 33554432) == 0 && hp_parts <= 256 ? 1 : 0;
     in.hp_shift = hp_shift;
@@ -2251,7 +2251,7 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             // many distinct keys (known from an earlier execution of this plan): the hash-partitioned form -- every pass
             // streams -- instead of the id build + dense passes (100 000 DOUBLE keys, 1 B rows: 24 ms that way)
             // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 17.0 ms,
-            // 100 000 keys 24.0 / 18.2, 300 000 keys 32.1 / 23.0, 1 000 000 keys 57 / 45.5 -- it pays from a few ten thousand keys on
+            // 100 000 keys 24.0 / 17.4, 300 000 keys 32.1 / 23.0, 1 000 000 keys 57 / 45.5 -- it pays from a few ten thousand keys on
             static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 25000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;

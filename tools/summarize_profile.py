@@ -131,6 +131,30 @@ def main(out, tag):
                 if in_step:
                     step_fetch += sum(f_t)
                     step_write += sum(w_t)
+        if not pj and dur:
+            # a tool run (no bench line): several executions, maybe of several forms, share kernel names -- list the dispatches
+            # in order, each with its own duration and its own counters (the n-th dispatch of a kernel in the trace pass is
+            # the n-th in the PMC passes: the same command)
+            rows = []
+            for f in find(os.path.join(case_dir, "trace"), "*kernel_trace.csv"):
+                rows += list(csv.DictReader(open(f)))
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            seen = {}
+            L.append("dispatch by dispatch (kernel-trace pass; FETCH_SIZE x2 and WRITE_SIZE of the same dispatch from the PMC passes):")
+            for r in rows:
+                k = short(r.get("Kernel_Name", ""))
+                i = seen.get(k, 0)
+                seen[k] = i + 1
+                if NOT_A_STEP.search(k) or k.startswith("__amd"):
+                    continue
+                f_, w_ = fetch.get(k, []), write.get(k, [])
+                d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                fb = 2 * f_[i] / 1e9 if i < len(f_) else float("nan")
+                wb = w_[i] / 1e9 if i < len(w_) else float("nan")
+                if d < 0.02 and fb + wb < 0.05:
+                    continue
+                L.append(f"  {k[:28]:28s} {d:8.3f} ms  grid {r.get('Grid_Size', r.get('Grid_Size_X', '?')):>8s} wg {r.get('Workgroup_Size', r.get('Workgroup_Size_X', '?')):>4s} "
+                         f"lds {r.get('LDS_Block_Size', '?'):>6s}  read {fb:7.2f} GB  written {wb:7.2f} GB  -> {(fb + wb) / d:6.2f} TB/s" if d > 0 else "")
         if pj and (step_fetch or step_write):
             hbm = (2 * step_fetch + step_write) / K_
             r = pj["roofline"]
