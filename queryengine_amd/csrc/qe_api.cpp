@@ -599,10 +599,11 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
     if (conj_order) in.conj_order = *conj_order;
     in.hp_parts = hp_parts;
     // records in 128-byte lines pad in units of 6 / 4 / 3 / 2 where {header, words} records of 32 bytes pad in units of 4: they win
-    // while a scatter tile holds long runs per partition (1 B rows, SELECT k, MIN(v), MAX(v), lines / records: 256 partitions, 30 000
-    // keys 17.0 / 19.5 ms, 100 000 keys 17.4 / 19.9; 512 partitions, 300 000 keys 24.9 / 23.0; 1024 partitions, 1 M keys 51.9 / 45.5).
-    // Debug bit 33554432: always {header, words} records.
-    in.hp_lines = (ctx->opts.tuning[5] & 33554432) == 0 && hp_parts <= 256 ? 1 : 0;
+    // while a scatter tile holds runs of several records per partition (1 B rows, SELECT k, MIN(v), MAX(v), lines / records: 256
+    // partitions, 100 000 keys 16.9 / 18.3 ms; 512 partitions, 500 000 keys 18.3 / 20.6, 1 M keys 24.6 / 26.7); with 1024 partitions
+    // the stage of a tile's lines no longer fits a 4 Ki-row tile.  Debug bit 33554432: always {header, words} records.
+    static const int lines_maxp = std::getenv("QE_HP_LINES_MAXP") ? std::atoi(std::getenv("QE_HP_LINES_MAXP")) : 512;
+    in.hp_lines = (ctx->opts.tuning[5] & 33554432) == 0 && hp_parts <= lines_maxp ? 1 : 0;
     in.hp_shift = hp_shift;
     in.geo = geometry_of(ctx);
     const bool wide = geo_cand == 1;
@@ -2250,8 +2251,8 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
         if (cg.hashed) {
             // many distinct keys (known from an earlier execution of this plan): the hash-partitioned form -- every pass
             // streams -- instead of the id build + dense passes (100 000 DOUBLE keys, 1 B rows: 24 ms that way)
-            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 17.0 ms,
-            // 100 000 keys 24.0 / 17.4, 300 000 keys 32.1 / 23.0, 1 000 000 keys 57 / 45.5 -- it pays from a few ten thousand keys on
+            // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 14.7 ms,
+            // 100 000 keys 24.0 / 15.3, 300 000 keys 32.1 / 17.8, 1 000 000 keys 57 / 24.4 -- it pays from a few ten thousand keys on
             static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 25000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;
@@ -2259,17 +2260,31 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 (hp_forced || (plan->known_keys >= hp_from && n >= (4ll << 20)))) {
                 // ONE workgroup aggregates a partition (128 partitions left half the chip idle: 21.8 ms for the aggregation of 1 B
                 // records).  Fewer partitions make longer runs per scatter tile -- less padding to whole lines --, more partitions keep
-                // the tables sparse: 256 up to ~130 000 keys, 512 up to ~400 000, 1024 beyond.  Buckets for ~5x the keys seen, 256 ..
-                // 2048 per partition: a wave leaves the probe loop after its LONGEST probe sequence, so the tables are kept sparse
-                // (100 000 keys, 1 B rows: 512 partitions x 512 / 1024 / 2048 buckets 28.8 / 22.1 / 21.0 ms, 256 x 2048 20.3 ms)
+                // the tables sparse.  Buckets for ~16x the keys seen, 256 .. 4096 per partition: a wave leaves the probe loop after its LONGEST
+                // probe sequence, so the tables are as sparse as the LDS allows (100 000 keys, 256 partitions x 1024 / 2048 / 4096 buckets:
+                // 23.4 / 17 / 15.5 ms)
                 static const int env_parts = std::getenv("QE_HP_PARTS") ? std::atoi(std::getenv("QE_HP_PARTS")) : 0;
                 static const int env_shift = std::getenv("QE_HP_SHIFT") ? std::atoi(std::getenv("QE_HP_SHIFT")) : 0;
-                static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 5;
+                static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 16;
                 const int64_t keys_seen = std::max<int64_t>(plan->known_keys, 1);
-                int P = hp_forced && plan->known_keys <= 0 ? 64 : keys_seen > 400000 ? 1024 : keys_seen > 130000 ? 512 : 256;
+                // the widest table a partition may have: entry = {first row, key words.., [count,] acc per aggregate}; MIN / MAX / SUM over
+                // inputs that cannot be NULL need no counter words -- {first row, key, MIN, MAX} is 32 bytes: 4096 buckets in 128 KiB
+                bool nocnt = true, keys_nullable = false;
+                for (int i = 0; i < nagg; i++)
+                    nocnt = nocnt && !cg.outs[(size_t)i].nullable && agg_fns[i] != QE_AGG_COUNT && agg_fns[i] != QE_AGG_AVG;
+                for (const OutSpec &ks : cg.keys) keys_nullable = keys_nullable || ks.nullable;
+                const int64_t entry_bytes = 8 * (1 + nkeys + (keys_nullable ? 1 : 0) + (nocnt ? 1 : 2) * nagg);
+                int max_shift = 12;
+                while (max_shift > 8 && (entry_bytes << max_shift) > 144 * 1024) max_shift--;
+                // few partitions = long runs per scatter tile = little padding, and the probe loop tolerates full tables better than the
+                // scatter tolerates short runs (1 M keys, 1 B rows: 512 partitions half full 24.6 ms, 1024 partitions a quarter full
+                // 37.1 ms; 500 000 keys: 256 partitions half full 22.6 ms, 512 a quarter full 18.3 ms): 256 partitions up to 30 %, 512
+                // up to 50 %, 1024 beyond
+                int P = keys_seen * 10 <= ((int64_t)256 << max_shift) * 3 ? 256 : keys_seen * 2 <= ((int64_t)512 << max_shift) ? 512 : 1024;
+                if (hp_forced && plan->known_keys <= 0) P = 64;
                 if (env_parts >= 2) P = env_parts;
                 int shift = 8;
-                while (shift < 11 && ((int64_t)P << shift) < keys_seen * env_fill) shift++;
+                while (shift < max_shift && ((int64_t)P << shift) < keys_seen * env_fill) shift++;
                 if (env_shift >= 6) shift = env_shift;
                 std::shared_ptr<Plan> hplan;
                 try {

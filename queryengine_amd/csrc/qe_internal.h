@@ -254,6 +254,7 @@ struct CodegenOutput {
     bool hp = false;             // hash-partitioned form of a hashed GROUP BY: dense partitioned passes over {partition, home bucket} pseudo
                                  // ids, records carry hp_key_words key words from value slot hp_key_slot on, entries = hash_words layout
     int hp_key_words = 0, hp_key_slot = 0, hp_shift = 11;   // 2^hp_shift buckets per partition
+    bool hp_nocnt = false;       // .. its table entries carry no counter words: no aggregate input can be NULL and none counts (MIN / MAX / SUM only)
     int hp_line_recs = 0;        // .. > 0: records live in 128-byte lines {R x value / key words, R x 32-bit row id, R x flag byte}; R = this
 };
 

@@ -250,6 +250,41 @@ def test_group_by_partitioned_sizes_around_tiles_and_chunks(n, oracle):
     ctx.close()
 
 
+def test_group_by_1m_keys_min_max_full_size_properties(oracle):
+    """SELECT k, MIN(v), MAX(v) over 1 B rows with 1 000 000 distinct DOUBLE keys (Tripdata.kt:27-31's shape at scale): the
+    hash-partitioned form with counter-less 32-byte table entries (no input can be NULL, nothing counts), 4096 buckets per
+    partition, records in 128-byte lines.  Properties: every key is a group; per group MIN <= MAX inside [0, 1); the smallest MIN
+    and the largest MAX are the independent global MIN / MAX; with 1000 values per key MIN and MAX sit near the ends; the first
+    groups are the keys of the first rows in their order (the oracle walks that window)."""
+    from queryengine_amd import ColumnExpression
+    from queryengine_amd import engine as E
+    from queryengine_amd.workloads import GenColumn
+    n, nkeys = 1_000_000_000, 1_000_000
+    ctx = E.Context(device=0)
+    gen = [GenColumn("k", D, N.GEN_F64_MOD, 0, modulus=nkeys), GenColumn("v", D, N.GEN_F64_UNIT, 1)]
+    K, V = ColumnExpression("k", 0, D), ColumnExpression("v", 1, D)
+    batch = E.DeviceBatch.generate(ctx, [c.spec(ctx) for c in gen], n)
+    (gmin, gmax), nsel = E.filter_aggregate(ctx, batch, None, [ctx.compile(V), ctx.compile(V)], [oracle.MIN, oracle.MAX])
+    assert nsel == n
+    for rep in range(2):
+        res = E.filter_groupby(ctx, batch, None, [ctx.compile(K)], [ctx.compile(V), ctx.compile(V)], [oracle.MIN, oracle.MAX])
+        cols, ngroups = res.to_columns(), res.count
+        res.free()
+        assert ngroups == nkeys
+        lo, hi = cols[1].data, cols[2].data
+        assert cols[1].valid is None or cols[1].valid.all()
+        assert (lo <= hi).all() and lo.min() == gmin and hi.max() == gmax and 0.0 <= gmin and gmax < 1.0
+        assert np.median(lo) < 0.005 and np.median(hi) > 0.995                    # 1000 uniform values per key
+        assert np.array_equal(np.sort(cols[0].data), np.arange(nkeys, dtype=np.float64))          # every key exactly once
+        m = 20_000
+        host = [batch.column_to_host(j, 0, m) for j in range(batch.ncols)]
+        want = oracle.filter_groupby(host, None, [K], [V, V], [oracle.MIN, oracle.MAX], oracle.BYTECODE_COMPILER)
+        assert [cols[0].value(i) for i in range(len(want))] == [w[0] for w in want]
+        assert ctx.last_form == (N.FORM_GROUPBY_HASHED if rep == 0 else N.FORM_GROUPBY_HASH_PARTITIONED)
+    batch.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind", ["dictionary_100k", "double_100k", "double_400k_hash_partitioned"])
 def test_group_by_full_size_properties(kind, oracle):
     """1 B rows through the partitioned passes (100 000 dictionary keys), through the dense-id path (100 000 distinct DOUBLE
@@ -352,7 +387,8 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
 
 @pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows",
                                   "double_specials_many_hash_partitioned", "int64_many_hash_partitioned", "mixed_keys_hash_partitioned",
-                                  "grows_hash_partitioned", "int64_many_hash_partitioned_records", "grows_hash_partitioned_records"])
+                                  "grows_hash_partitioned", "int64_many_hash_partitioned_records", "grows_hash_partitioned_records",
+                                  "nocount_hash_partitioned"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
@@ -391,6 +427,11 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         k = Column(I64, rng.integers(-2 ** 62, 2 ** 62, 150_000)[rng.integers(0, 150_000, n)], rng.random(n) > 0.01)
         keys = [ColumnExpression("k", 0, I64)]
         cols = [k]
+    elif case == "nocount":
+        n = 400_003                                           # ~40 k keys, nothing nullable, nothing that counts: table entries without counters
+        k = Column(D, np.round(rng.normal(0, 12000, n)))
+        keys = [ColumnExpression("k", 0, D)]
+        cols = [k]
     elif case == "grows":
         n = 900_001                                           # ~570 k distinct keys: the 65 536-entry table grows twice
         k = Column(I32, rng.integers(0, 1_000_000, n).astype(np.int32))
@@ -405,13 +446,15 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         keys = [ColumnExpression("s", 0, S), FunctionExpression(Function.MUL, [ColumnExpression("k", 1, D), NumericLiteralExpression(0.5)], D),
                 ColumnExpression("b", 2, B)]
         cols = [s, k, b]
-    x = Column(D, np.round(rng.normal(0, 100, n)), rng.random(n) > 0.2)       # integer valued: sums exact in any order
+    x = Column(D, np.round(rng.normal(0, 100, n)), None if case == "nocount" else rng.random(n) > 0.2)   # integer valued: sums exact in any order
     y = Column(I64, rng.integers(-1000, 1000, n))
     nc = len(cols)
     X, Y = ColumnExpression("x", nc, D), ColumnExpression("y", nc + 1, I64)
     cols = cols + [x, y]
     exprs = [X, X, X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)]
     aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
+    if case == "nocount":
+        exprs, aggs = [X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)], [oracle.SUM, oracle.MIN, oracle.MAX, oracle.SUM]
     flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
     batch = E.DeviceBatch.from_columns(ctx, cols)
     forms = []
@@ -431,7 +474,7 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         assert forms[-1] == N.FORM_GROUPBY_HASH_PARTITIONED, forms
         # (64 partitions hold 131 072 buckets: the 150 000 / 570 000 keys of "int64_many" / "grows" overflow them once, that
         # execution falls back and reports the key count, the next one sizes its partitions from it)
-        assert case in ("grows", "int64_many") or all(f_ == N.FORM_GROUPBY_HASH_PARTITIONED for f_ in forms), forms
+        assert case in ("grows", "int64_many", "nocount") or all(f_ == N.FORM_GROUPBY_HASH_PARTITIONED for f_ in forms), forms
     else:
         assert all(f_ == N.FORM_GROUPBY_HASHED for f_ in forms), forms
     batch.free()
