@@ -2252,8 +2252,9 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             // many distinct keys (known from an earlier execution of this plan): the hash-partitioned form -- every pass
             // streams -- instead of the id build + dense passes (100 000 DOUBLE keys, 1 B rows: 24 ms that way)
             // measured, SELECT k, MIN(v), MAX(v) over 1 B rows, id build + dense passes against this form: 30 000 keys 21 / 14.7 ms,
-            // 100 000 keys 24.0 / 15.3, 300 000 keys 32.1 / 17.8, 1 000 000 keys 57 / 24.4 -- it pays from a few ten thousand keys on
-            static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 25000;
+            // 100 000 keys 24.0 / 15.3, 300 000 keys 32.1 / 17.8, 1 000 000 keys 57 / 24.4 ; below 25 000 keys, this form / ids:
+            // 20 000 keys 14.9 / 20.2, 10 000 keys 15.9 / 16.9, 5000 keys 16.3 / 16.8, 3000 keys 17.2 / 18.3 (fewer fit the LDS-privatised table)
+            static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 4000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;
             if (!hp_never && !plan->hp_failed && n > 0 && n < (1ll << 32) && nkeys <= 4 && nagg <= 8 &&
@@ -2267,13 +2268,13 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 static const int env_shift = std::getenv("QE_HP_SHIFT") ? std::atoi(std::getenv("QE_HP_SHIFT")) : 0;
                 static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 16;
                 const int64_t keys_seen = std::max<int64_t>(plan->known_keys, 1);
-                // the widest table a partition may have: entry = {first row, key words.., [count,] acc per aggregate}; MIN / MAX / SUM over
-                // inputs that cannot be NULL need no counter words -- {first row, key, MIN, MAX} is 32 bytes: 4096 buckets in 128 KiB
-                bool nocnt = true, keys_nullable = false;
-                for (int i = 0; i < nagg; i++)
-                    nocnt = nocnt && !cg.outs[(size_t)i].nullable && agg_fns[i] != QE_AGG_COUNT && agg_fns[i] != QE_AGG_AVG;
+                // the widest table a partition may have: entry = {first row, key words.., the counters and accumulators the plan needs}:
+                // {first row, key, MIN, MAX} and {first row, key, count, SUM} are 32 bytes: 4096 buckets in 128 KiB
+                bool keys_nullable = false;
+                std::vector<char> agg_nullable;
+                for (int i = 0; i < nagg; i++) agg_nullable.push_back(cg.outs[(size_t)i].nullable ? 1 : 0);
                 for (const OutSpec &ks : cg.keys) keys_nullable = keys_nullable || ks.nullable;
-                const int64_t entry_bytes = 8 * (1 + nkeys + (keys_nullable ? 1 : 0) + (nocnt ? 1 : 2) * nagg);
+                const int64_t entry_bytes = 8 * (1 + nkeys + (keys_nullable ? 1 : 0) + hp_entry_layout(agg_nullable, agg_fns, nagg).words);
                 int max_shift = 12;
                 while (max_shift > 8 && (entry_bytes << max_shift) > 144 * 1024) max_shift--;
                 // few partitions = long runs per scatter tile = little padding, and the probe loop tolerates full tables better than the

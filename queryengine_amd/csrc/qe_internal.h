@@ -111,6 +111,40 @@ private:
     std::unordered_map<void *, size_t> live_;
 };
 
+// Table entry of the hash-partitioned GROUP BY behind its key words: only the words the plan needs.  An aggregate's counter says
+// whether it saw a non-null value, or counts (COUNT, AVG): aggregates over inputs that cannot be NULL share one (the first such
+// aggregate's), and that one exists only when something counts; a nullable aggregate keeps its own.  COUNT has no accumulator.
+// cw[i] / aw[i] = word of aggregate i's counter / accumulator (1-based behind the key words; 0 = none: the count reads as 1).
+struct HpEntryLayout {
+    std::vector<int> cw, aw, init_of;   // init_of[w - 1] = the aggregate whose accumulator word w is (-1: a counter)
+    int words = 0;
+};
+inline HpEntryLayout hp_entry_layout(const std::vector<char> &nullable, const int32_t *agg_fns, int nagg) {
+    HpEntryLayout L;
+    L.cw.assign((size_t)nagg, 0);
+    L.aw.assign((size_t)nagg, 0);
+    int shared = -1;
+    bool shared_counts = false;
+    for (int i = 0; i < nagg; i++)
+        if (!nullable[(size_t)i]) {
+            if (shared < 0) shared = i;
+            shared_counts = shared_counts || agg_fns[i] == QE_AGG_COUNT || agg_fns[i] == QE_AGG_AVG;
+        }
+    for (int i = 0; i < nagg; i++) {
+        if (nullable[(size_t)i] || (i == shared && shared_counts)) {
+            L.cw[(size_t)i] = ++L.words;
+            L.init_of.push_back(-1);
+        }
+        if (agg_fns[i] != QE_AGG_COUNT) {
+            L.aw[(size_t)i] = ++L.words;
+            L.init_of.push_back(i);
+        }
+    }
+    for (int i = 0; i < nagg; i++)
+        if (!nullable[(size_t)i] && i != shared) L.cw[(size_t)i] = shared >= 0 ? L.cw[(size_t)shared] : 0;
+    return L;
+}
+
 struct Column {
     int type = 0;
     void *data = nullptr;            // device
@@ -254,7 +288,6 @@ struct CodegenOutput {
     bool hp = false;             // hash-partitioned form of a hashed GROUP BY: dense partitioned passes over {partition, home bucket} pseudo
                                  // ids, records carry hp_key_words key words from value slot hp_key_slot on, entries = hash_words layout
     int hp_key_words = 0, hp_key_slot = 0, hp_shift = 11;   // 2^hp_shift buckets per partition
-    bool hp_nocnt = false;       // .. its table entries carry no counter words: no aggregate input can be NULL and none counts (MIN / MAX / SUM only)
     int hp_line_recs = 0;        // .. > 0: records live in 128-byte lines {R x value / key words, R x 32-bit row id, R x flag byte}; R = this
 };
 

@@ -296,7 +296,8 @@ def test_group_by_full_size_properties(kind, oracle):
     from queryengine_amd import engine as E
     from queryengine_amd.workloads import GenColumn
     n, nkeys = 1_000_000_000, (400_000 if kind.startswith("double_400k") else 100_000)
-    ctx = E.Context(device=0)
+    # "double_100k" keeps the dense-id path (debug bit 16777216 forbids the hash-partitioned form, which would take over at this key count)
+    ctx = E.Context(device=0, tuning=[0, 0, 0, 0, 0, 16777216] if kind == "double_100k" else [])
     if kind == "dictionary_100k":
         d = ["k%06d" % i for i in range(nkeys)]
         gen = [GenColumn("k", S, N.GEN_DICT_MOD, 0, modulus=nkeys, dictionary=d), GenColumn("v", D, N.GEN_F64_UNIT, 1)]
@@ -326,6 +327,8 @@ def test_group_by_full_size_properties(kind, oracle):
         assert head == [w[0] for w in want]
         if kind.startswith("double_400k"):
             assert ctx.last_form == (N.FORM_GROUPBY_HASHED if rep == 0 else N.FORM_GROUPBY_HASH_PARTITIONED)
+        elif kind == "double_100k":
+            assert ctx.last_form == N.FORM_GROUPBY_HASHED
     batch.free()
     ctx.close()
 
@@ -428,7 +431,7 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         keys = [ColumnExpression("k", 0, I64)]
         cols = [k]
     elif case == "nocount":
-        n = 400_003                                           # ~40 k keys, nothing nullable, nothing that counts: table entries without counters
+        n = 400_003                                           # ~40 k keys, nothing nullable, nothing that counts: table entries without counter words
         k = Column(D, np.round(rng.normal(0, 12000, n)))
         keys = [ColumnExpression("k", 0, D)]
         cols = [k]
