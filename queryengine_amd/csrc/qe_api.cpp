@@ -693,17 +693,23 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         // the scatter pass sorts a workgroup tile's records in ONE LDS stage: 8 waves x 512 rows x 32-byte records = 128 KiB (one
         // workgroup per CU) was the fastest of the shapes measured on 100 000 DOUBLE keys, 512 partitions: 4 waves x 1024 rows
         // 31.4 ms, 4 x 512 29.0, 8 x 512 25.6, 8 x 256 29.3; wider records take fewer rows per wave
-        const size_t rec = (size_t)(1 + plan->cg.nvals) * 8;
         in.geo.threads = 512;
         int u = 4;
-        if (plan->cg.hp_line_recs) {   // the stage holds the tile's LINES: every partition's run padded to whole lines, in the worst case
-            const size_t R = (size_t)plan->cg.hp_line_recs, P = (size_t)plan->cg.nparts;
-            auto lds = [&](int uu) {
-                const size_t tile = (size_t)(in.geo.threads / 64) * 128 * uu, lines = (tile + (R - 1) * P + R - 1) / R;
-                return lines * 132 + ((P + 3) & ~(size_t)3) * 16 + 64;
-            };
-            while (u > 1 && lds(u) > 156 * 1024) u /= 2;
+        auto lines_lds = [&](int uu) {   // the stage holds the tile's LINES: every partition's run padded to whole lines, in the worst case
+            const size_t R = (size_t)std::max(1, plan->cg.hp_line_recs), P = (size_t)plan->cg.nparts;
+            const size_t tile = (size_t)(in.geo.threads / 64) * 128 * uu, lines = (tile + (R - 1) * P + R - 1) / R;
+            return lines * 132 + ((P + 3) & ~(size_t)3) * 16 + 64;
+        };
+        if (plan->cg.hp_line_recs && lines_lds(4) > 156 * 1024) {
+            // wide records (two or three per line) in many partitions: the lines' stage would force a smaller tile, i.e. shorter runs and
+            // more padding than the {header, words} records have
+            in.hp_lines = 0;
+            plan->cg = generate_fused_source(in);
+        }
+        if (plan->cg.hp_line_recs) {
+            while (u > 1 && lines_lds(u) > 156 * 1024) u /= 2;
         } else {
+            const size_t rec = (size_t)(1 + plan->cg.nvals) * 8;
             while (u > 1 && (size_t)(in.geo.threads / 64) * 128 * u * rec > 128 * 1024) u /= 2;
         }
         in.geo.unroll = u;
