@@ -697,8 +697,8 @@ std::shared_ptr<Plan> get_plan(qe_ctx *ctx, const qe_batch *batch, const qe_expr
         int u = 4;
         auto lines_lds = [&](int uu) {   // the stage holds the tile's LINES: every partition's run padded to whole lines, in the worst case
             const size_t R = (size_t)std::max(1, plan->cg.hp_line_recs), P = (size_t)plan->cg.nparts;
-            const size_t tile = (size_t)(in.geo.threads / 64) * 128 * uu, lines = (tile + (R - 1) * P + R - 1) / R;
-            return lines * 132 + ((P + 3) & ~(size_t)3) * 16 + 64;
+            const size_t tile = (size_t)(in.geo.threads / 64) * 128 * uu, lines = (tile + (P <= 256 ? 2 : 1) * (R - 1) * P + R - 1) / R;
+            return lines * 132 + ((P + 3) & ~(size_t)3) * (P <= 256 ? 24 : 16) + 64;   // (<= 256 partitions: the carry -- every run may also START with waiting records)
         };
         if (plan->cg.hp_line_recs && lines_lds(4) > 156 * 1024) {
             // wide records (two or three per line) in many partitions: the lines' stage would force a smaller tile, i.e. shorter runs and
