@@ -391,7 +391,7 @@ def _rows_equal(got, want, nkeys, aggs, oracle):
 @pytest.mark.parametrize("case", ["double_specials", "double_specials_many", "int64_many", "int64_many_global_atomics", "mixed_keys", "grows",
                                   "double_specials_many_hash_partitioned", "int64_many_hash_partitioned", "mixed_keys_hash_partitioned",
                                   "grows_hash_partitioned", "int64_many_hash_partitioned_records", "grows_hash_partitioned_records",
-                                  "nocount_hash_partitioned"])
+                                  "nocount_hash_partitioned", "onevalue_hash_partitioned"])
 def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     """GROUP BY over DOUBLE / INT64 / INT32 keys (GroupByAggregationOperator.kt:33-37 groups on any boxed key tuple;
     Tripdata.kt:27-31 groups by a DOUBLE column): the hashed form.  Key equality is List<Any?>.equals -> Double.equals
@@ -430,6 +430,11 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         k = Column(I64, rng.integers(-2 ** 62, 2 ** 62, 150_000)[rng.integers(0, 150_000, n)], rng.random(n) > 0.01)
         keys = [ColumnExpression("k", 0, I64)]
         cols = [k]
+    elif case == "onevalue":
+        n = 500_009                                           # one key word + one value word (6 records per line), a chunk boundary inside
+        k = Column(D, np.round(rng.normal(0, 9000, n)))
+        keys = [ColumnExpression("k", 0, D)]
+        cols = [k]
     elif case == "nocount":
         n = 400_003                                           # ~40 k keys, nothing nullable, nothing that counts: table entries without counter words
         k = Column(D, np.round(rng.normal(0, 12000, n)))
@@ -458,6 +463,8 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     aggs = [oracle.SUM, oracle.MIN, oracle.MAX, oracle.COUNT, oracle.AVG, oracle.SUM]
     if case == "nocount":
         exprs, aggs = [X, X, X, FunctionExpression(Function.ADD, [Y, Y], I64)], [oracle.SUM, oracle.MIN, oracle.MAX, oracle.SUM]
+    if case == "onevalue":
+        exprs, aggs = [X, X, X], [oracle.COUNT, oracle.AVG, oracle.MAX]
     flt = FunctionExpression(Function.CMP_LT, [Y, NumericLiteralExpression(500.0)], B)
     batch = E.DeviceBatch.from_columns(ctx, cols)
     forms = []
@@ -477,7 +484,7 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
         assert forms[-1] == N.FORM_GROUPBY_HASH_PARTITIONED, forms
         # (64 partitions hold 131 072 buckets: the 150 000 / 570 000 keys of "int64_many" / "grows" overflow them once, that
         # execution falls back and reports the key count, the next one sizes its partitions from it)
-        assert case in ("grows", "int64_many", "nocount") or all(f_ == N.FORM_GROUPBY_HASH_PARTITIONED for f_ in forms), forms
+        assert case in ("grows", "int64_many", "nocount", "onevalue") or all(f_ == N.FORM_GROUPBY_HASH_PARTITIONED for f_ in forms), forms
     else:
         assert all(f_ == N.FORM_GROUPBY_HASHED for f_ in forms), forms
     batch.free()
