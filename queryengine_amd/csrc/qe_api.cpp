@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -1443,7 +1444,7 @@ void append_key_columns(qe_ctx *ctx, const CodegenOutput &cg, qe_result *res, in
 // (2) the dense group-by -- LDS-privatised table or the partitioned passes -- runs on the id column; (3) the ids of the result
 // rows are turned back into key values.  nullptr: more keys than a dense table takes (the caller keeps the global-atomic form).
 qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const qe_expr *filter, const qe_expr *const *exprs,
-                           const int32_t *agg_fns, int32_t nagg) {
+                           const int32_t *agg_fns, int32_t nagg, bool *many_keys) {
     const CodegenOutput &cg = plan.cg;
     const int NK = (int)cg.keys.size(), BW = NK == 1 ? 2 : 3 + NK;   // single-key plans: 16-byte entries {key, state | null bits | id}
     const int64_t n = batch->nrows;
@@ -1487,6 +1488,10 @@ qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan,
         }
         const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
         if (hc[1] != 0) {   // more than half full: a bigger table, again (the launch stopped at once: an attempt costs little)
+            if (many_keys && plan.id_capacity <= 0) {   // the first table of a plan that knows nothing yet: the caller takes over
+                *many_keys = true;
+                return nullptr;
+            }
             if (C >= (1ll << 22)) return nullptr;
             C *= 4;
             continue;
@@ -1570,7 +1575,25 @@ qe_result *finish_hashed_groups(qe_ctx *ctx, const CodegenOutput &cg, const std:
     std::vector<std::pair<unsigned long long, int64_t>> order;
     order.reserve((size_t)m);
     for (int64_t g = 0; g < m; g++) order.emplace_back(dense[(size_t)g * W + ACC], g);
-    std::sort(order.begin(), order.end());
+    if (m < 4096) {
+        std::sort(order.begin(), order.end());
+    } else {
+        // first rows are distinct row ids < 2^42: three stable passes of a 14-bit radix sort (std::sort took ~80 of the 125 ms the
+        // host spent finishing 1 M groups)
+        std::vector<std::pair<unsigned long long, int64_t>> tmp(order.size());
+        std::vector<size_t> cnt((size_t)1 << 14);
+        unsigned long long all = 0;
+        for (const auto &o : order) all |= o.first;
+        for (int pass = 0; pass < 5 && (all >> (14 * pass)) != 0; pass++) {
+            const int sh = 14 * pass;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (const auto &o : order) cnt[(size_t)((o.first >> sh) & 0x3fffull)]++;
+            size_t run = 0;
+            for (size_t &c : cnt) { const size_t t = c; c = run; run += t; }
+            for (const auto &o : order) tmp[cnt[(size_t)((o.first >> sh) & 0x3fffull)]++] = o;
+            order.swap(tmp);
+        }
+    }
     std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
     res->count = m;
     res->capacity = m;
@@ -1624,14 +1647,17 @@ qe_result *finish_hashed_groups(qe_ctx *ctx, const CodegenOutput &cg, const std:
     return res.release();
 }
 
+// `many_keys` (optional): set -- and nullptr returned, nothing decided for the plan -- when the id build's FIRST table fills up
+// (more than 32 768 keys): the caller has a better form for that many keys than a grown id table.
 qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &plan, const qe_expr *filter, const qe_expr *const *exprs,
-                              const int32_t *agg_fns, int32_t nagg) {
+                              const int32_t *agg_fns, int32_t nagg, bool *many_keys) {
     const CodegenOutput &cg = plan.cg;
     const bool ids_allowed = (ctx->opts.tuning[5] & 131072) == 0 && batch->nrows < (1ll << 32);   // debug bit 131072: keep the global-atomic form
     bool ids_failed = plan.ids_overflow;   // more keys than a dense table takes, found out by an earlier execution: straight to the global-atomic form
     if (plan.use_ids && ids_allowed && !ids_failed) {
-        qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
+        qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg, many_keys);
         if (r) return r;
+        if (many_keys && *many_keys) return nullptr;
         plan.ids_overflow = ids_failed = true;
         plan.use_ids = false;
     }
@@ -1670,8 +1696,9 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
             if (hc[1] == 4) {   // the keys do not fit the LDS table: dense ids from now on (this execution included)
                 plan.use_ids = true;
-                qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg);
+                qe_result *r = run_groupby_ids(ctx, batch, plan, filter, exprs, agg_fns, nagg, many_keys);
                 if (r) return r;
+                if (many_keys && *many_keys) return nullptr;
                 ids_failed = true;   // more keys than a dense table takes: the global-atomic form after all -- and remembered,
                 plan.ids_overflow = true;   // so that later executions do not run the failing id build again
                 plan.use_ids = false;
@@ -1751,8 +1778,14 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
     if (m_records > 0) {
         p.l1 = d_start;
         const int rec_words = 1 + cg.nvals;
+        static const bool dbg_times = std::getenv("QE_DEBUG_TIMES") != nullptr;
+        const auto t_alloc0 = std::chrono::steady_clock::now();
         if (cg.hp_line_recs) p.desc = (unsigned long long *)talloc((size_t)(m_records / cg.hp_line_recs + 2) * 128);   // whole lines + the spare line
         else p.desc = (unsigned long long *)talloc((size_t)(m_records + 16) * 8 * rec_words);
+        if (dbg_times)
+            std::fprintf(stderr, "run_groupby_hp: record array of %.2f GB from the pool in %.1f ms\n",
+                         (cg.hp_line_recs ? (double)(m_records / cg.hp_line_recs + 2) * 128 : (double)(m_records + 16) * 8 * rec_words) / 1e9,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count());
         const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)device_cus(ctx->device) * (plan->geo.threads >= 512 ? 1 : kScatterWgsPerCu)));
         hipDeviceptr_t dbg = nullptr;
         size_t dbg_bytes = 0;
@@ -2263,26 +2296,54 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
             static const int64_t hp_from = std::getenv("QE_HP_FROM") ? std::atoll(std::getenv("QE_HP_FROM")) : 4000;
             const bool hp_forced = (ctx->opts.tuning[5] & 8388608) != 0, hp_never = (ctx->opts.tuning[5] & 16777216) != 0;
             const int64_t n = batch->nrows;
-            if (!hp_never && !plan->hp_failed && n > 0 && n < (1ll << 32) && nkeys <= 4 && nagg <= 8 &&
-                (hp_forced || (plan->known_keys >= hp_from && n >= (4ll << 20)))) {
-                // ONE workgroup aggregates a partition (128 partitions left half the chip idle: 21.8 ms for the aggregation of 1 B
-                // records).  Fewer partitions make longer runs per scatter tile -- less padding to whole lines --, more partitions keep
-                // the tables sparse.  Buckets for ~16x the keys seen, 256 .. 4096 per partition: a wave leaves the probe loop after its LONGEST
-                // probe sequence, so the tables are as sparse as the LDS allows (100 000 keys, 256 partitions x 1024 / 2048 / 4096 buckets:
-                // 23.4 / 17 / 15.5 ms)
-                static const int env_parts = std::getenv("QE_HP_PARTS") ? std::atoi(std::getenv("QE_HP_PARTS")) : 0;
-                static const int env_shift = std::getenv("QE_HP_SHIFT") ? std::atoi(std::getenv("QE_HP_SHIFT")) : 0;
-                static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 16;
-                const int64_t keys_seen = std::max<int64_t>(plan->known_keys, 1);
-                // the widest table a partition may have: entry = {first row, key words.., the counters and accumulators the plan needs}:
-                // {first row, key, MIN, MAX} and {first row, key, count, SUM} are 32 bytes: 4096 buckets in 128 KiB
+            const bool hp_possible = !hp_never && !plan->hp_failed && n > 0 && n < (1ll << 32) && nkeys <= 4 && nagg <= 8;
+            static const int env_parts = std::getenv("QE_HP_PARTS") ? std::atoi(std::getenv("QE_HP_PARTS")) : 0;
+            static const int env_shift = std::getenv("QE_HP_SHIFT") ? std::atoi(std::getenv("QE_HP_SHIFT")) : 0;
+            static const int env_fill = std::getenv("QE_HP_FILL") ? std::atoi(std::getenv("QE_HP_FILL")) : 16;
+            // the widest table a partition may have: entry = {first row, key words.., the counters and accumulators the plan needs}:
+            // {first row, key, MIN, MAX} and {first row, key, count, SUM} are 32 bytes: 4096 buckets in 128 KiB
+            int max_shift = 12;
+            {
                 bool keys_nullable = false;
                 std::vector<char> agg_nullable;
                 for (int i = 0; i < nagg; i++) agg_nullable.push_back(cg.outs[(size_t)i].nullable ? 1 : 0);
                 for (const OutSpec &ks : cg.keys) keys_nullable = keys_nullable || ks.nullable;
                 const int64_t entry_bytes = 8 * (1 + nkeys + (keys_nullable ? 1 : 0) + hp_entry_layout(agg_nullable, agg_fns, nagg).words);
-                int max_shift = 12;
                 while (max_shift > 8 && (entry_bytes << max_shift) > 144 * 1024) max_shift--;
+            }
+            // one attempt with P partitions of 2^shift buckets: the result, or nullptr when some partition's table filled up (or the form
+            // is not to be had: hp_failed)
+            auto try_hp = [&](int P, int shift) -> qe_result * {
+                std::shared_ptr<Plan> hplan;
+                try {
+                    hplan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true, keys, nkeys, false, false, nullptr, P, shift);
+                } catch (const Error &) {   // e.g. an entry too wide for the LDS table: the other forms stay
+                    plan->hp_failed = true;
+                    return nullptr;
+                }
+                if (!hplan || !hplan->cg.hp) return nullptr;
+                qe_result *r = nullptr;
+                try {
+                    r = run_groupby_hp(ctx, batch, hplan, agg_fns, nagg);
+                } catch (const Error &e) {
+                    // its record array (21 - 64 bytes per kept row) did not fit beside the batch: the dense-id path needs 4 + 16
+                    // bytes per row -- this plan stays with that one (run_groupby_hp releases what it had allocated)
+                    if (e.code != QE_ERR_OOM) throw;
+                    plan->hp_failed = true;
+                }
+                if (r) {
+                    plan->known_keys = r->count;
+                    ctx->last_form = QE_FORM_GROUPBY_HASH_PARTITIONED;
+                }
+                return r;
+            };
+            if (hp_possible && (hp_forced || (plan->known_keys >= hp_from && n >= (4ll << 20)))) {
+                // ONE workgroup aggregates a partition (128 partitions left half the chip idle: 21.8 ms for the aggregation of 1 B
+                // records).  Fewer partitions make longer runs per scatter tile -- less padding to whole lines --, more partitions keep
+                // the tables sparse.  Buckets for ~16x the keys seen, 256 .. 4096 per partition: a wave leaves the probe loop after its LONGEST
+                // probe sequence, so the tables are as sparse as the LDS allows (100 000 keys, 256 partitions x 1024 / 2048 / 4096 buckets:
+                // 23.4 / 17 / 15.5 ms)
+                const int64_t keys_seen = std::max<int64_t>(plan->known_keys, 1);
                 // few partitions = long runs per scatter tile = little padding, and the probe loop tolerates full tables better than the
                 // scatter tolerates short runs (1 M keys, 1 B rows: 512 partitions half full 24.6 ms, 1024 partitions a quarter full
                 // 37.1 ms; 500 000 keys: 256 partitions half full 22.6 ms, 512 a quarter full 18.3 ms): 256 partitions up to 30 %, 512
@@ -2293,26 +2354,26 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 int shift = 8;
                 while (shift < max_shift && ((int64_t)P << shift) < keys_seen * env_fill) shift++;
                 if (env_shift >= 6) shift = env_shift;
-                std::shared_ptr<Plan> hplan;
-                try {
-                    hplan = get_plan(ctx, batch, filter, exprs, nagg, agg_fns, true, keys, nkeys, false, false, nullptr, P, shift);
-                } catch (const Error &) {   // e.g. an entry too wide for the LDS table: the other forms stay
-                    plan->hp_failed = true;
+                if (qe_result *r = try_hp(P, shift)) {
+                    *out = r;
+                    return;
                 }
-                if (hplan && hplan->cg.hp) {
-                    qe_result *r = run_groupby_hp(ctx, batch, hplan, agg_fns, nagg);
-                    if (r) {
-                        plan->known_keys = r->count;
-                        ctx->last_form = QE_FORM_GROUPBY_HASH_PARTITIONED;
-                        *out = r;
-                        return;
-                    }
-                    // some partition's table filled up: with 1024 partitions there is nothing larger to try; otherwise the run below
-                    // reports how many keys there are and the next execution sizes its partitions from that
-                    if (P >= 1024) plan->hp_failed = true;
-                }
+                // some partition's table filled up: with 1024 partitions there is nothing larger to try; otherwise the run below
+                // reports how many keys there are and the next execution sizes its partitions from that
+                if (P >= 1024) plan->hp_failed = true;
             }
-            *out = run_groupby_hashed(ctx, batch, *plan, filter, exprs, agg_fns, nagg);
+            // The FIRST execution of a plan does not know its keys.  The LDS tables and the id build find out cheaply that there are
+            // many (their launches stop at once when a table fills up: more than 32 768 keys fill the id build's first table); from
+            // there the hash-partitioned form takes over with the widest tables -- 256, then 512, then 1024 partitions when a table
+            // overflows -- instead of growing the id table (100 000 keys, 1 B rows: a first execution of 48 ms that way).
+            bool many_keys = false;
+            const bool first_hp = hp_possible && !hp_forced && plan->known_keys < 0 && plan->id_capacity <= 0 && n >= (4ll << 20);
+            *out = run_groupby_hashed(ctx, batch, *plan, filter, exprs, agg_fns, nagg, first_hp ? &many_keys : nullptr);
+            if (!*out && many_keys) {
+                for (int P = 256; P <= 1024 && !*out && !plan->hp_failed; P *= 2) *out = try_hp(P, max_shift);
+                if (*out) return;
+                *out = run_groupby_hashed(ctx, batch, *plan, filter, exprs, agg_fns, nagg, nullptr);   // more keys than 1024 tables hold
+            }
             if (*out) plan->known_keys = (*out)->count;
             ctx->last_form = QE_FORM_GROUPBY_HASHED;
             return;

@@ -280,7 +280,9 @@ def test_group_by_1m_keys_min_max_full_size_properties(oracle):
         host = [batch.column_to_host(j, 0, m) for j in range(batch.ncols)]
         want = oracle.filter_groupby(host, None, [K], [V, V], [oracle.MIN, oracle.MAX], oracle.BYTECODE_COMPILER)
         assert [cols[0].value(i) for i in range(len(want))] == [w[0] for w in want]
-        assert ctx.last_form == (N.FORM_GROUPBY_HASHED if rep == 0 else N.FORM_GROUPBY_HASH_PARTITIONED)
+        # (the first execution too: the id build's first table fills up -- more than 32 768 keys -- and this form takes over with the
+        # widest tables, 256 partitions first, then 512)
+        assert ctx.last_form == N.FORM_GROUPBY_HASH_PARTITIONED
     batch.free()
     ctx.close()
 
@@ -288,8 +290,7 @@ def test_group_by_1m_keys_min_max_full_size_properties(oracle):
 @pytest.mark.parametrize("kind", ["dictionary_100k", "double_100k", "double_400k_hash_partitioned"])
 def test_group_by_full_size_properties(kind, oracle):
     """1 B rows through the partitioned passes (100 000 dictionary keys), through the dense-id path (100 000 distinct DOUBLE
-    keys) and through the hash-partitioned form (400 000 distinct DOUBLE keys: chosen from the second execution on, once the
-    plan knows how many keys there are): properties that do not need a second engine -- every key is a group, COUNT adds up to the rows the filter keeps (an
+    keys) and through the hash-partitioned form (400 000 distinct DOUBLE keys): properties that do not need a second engine -- every key is a group, COUNT adds up to the rows the filter keeps (an
     independent filter + COUNT aggregate), SUM adds up to the independent SUM within the reassociation bound, the first
     groups are the keys of the first rows in their order of first appearance (the oracle walks that window row by row)."""
     from queryengine_amd import ColumnExpression, Function, FunctionExpression, NumericLiteralExpression
@@ -326,7 +327,7 @@ def test_group_by_full_size_properties(kind, oracle):
         head = [cols[0].value(i) for i in range(len(want))]
         assert head == [w[0] for w in want]
         if kind.startswith("double_400k"):
-            assert ctx.last_form == (N.FORM_GROUPBY_HASHED if rep == 0 else N.FORM_GROUPBY_HASH_PARTITIONED)
+            assert ctx.last_form == N.FORM_GROUPBY_HASH_PARTITIONED    # from the first execution on (more than 32 768 keys)
         elif kind == "double_100k":
             assert ctx.last_form == N.FORM_GROUPBY_HASHED
     batch.free()
