@@ -1569,7 +1569,7 @@ qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan,
 // The groups of a hashed GROUP BY, finished on the host: `dense` holds m entries of cg.hash_words words {state, null bits, key
 // words.., first row, (count, acc)..}.  Insertion order = ascending first row (LinkedHashMap, GroupByAggregationOperator.kt:22);
 // accumulators finish as Accumulators.kt:26-107 says.
-qe_result *finish_hashed_groups(qe_ctx *ctx, const CodegenOutput &cg, const std::vector<unsigned long long> &dense, int64_t m,
+qe_result *finish_hashed_groups(qe_ctx *ctx, const CodegenOutput &cg, const unsigned long long *dense, int64_t m,
                                 const int32_t *agg_fns, int32_t nagg) {
     const int W = cg.hash_words, NK = (int)cg.keys.size(), ACC = 2 + NK;
     std::vector<std::pair<unsigned long long, int64_t>> order;
@@ -1635,10 +1635,10 @@ qe_result *finish_hashed_groups(qe_ctx *ctx, const CodegenOutput &cg, const std:
             vals[j] = v;
         }
         oc.nullable = any_null;
-        keep_vals.push_back(vals);
+        keep_vals.push_back(std::move(vals));
         oc.data = upload(keep_vals.back().data(), (size_t)m * 8);
         if (any_null) {
-            keep64.push_back(valid);
+            keep64.push_back(std::move(valid));
             oc.validity = (uint64_t *)upload(keep64.back().data(), words * 8);
         }
         res->cols.push_back(oc);
@@ -1728,7 +1728,7 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
             break;
         }
     }
-    return finish_hashed_groups(ctx, cg, dense, m, agg_fns, nagg);
+    return finish_hashed_groups(ctx, cg, dense.data(), m, agg_fns, nagg);
 }
 
 // HASH-PARTITIONED form of a hashed GROUP BY with many distinct keys (round 3): count -> scan -> scatter of
@@ -1773,7 +1773,9 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
     start[P] = m_records;
     if (m_records >= (1ull << 32)) return nullptr;   // record positions are 32-bit in the scatter pass
     QE_HIP(hipMemcpyAsync(d_start, start.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<unsigned long long> dense;
+    // the groups' entries come back through pinned staging (64 MB for 1 M groups: 1.5 ms instead of ~15 ms into pageable memory)
+    unsigned long long *dense = nullptr;
+    struct PG { qe_ctx *c; unsigned long long **p; ~PG() { if (*p) c->pinned.release(*p); } } pg{ctx, &dense};
     int64_t m = 0;
     if (m_records > 0) {
         p.l1 = d_start;
@@ -1818,8 +1820,10 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
         const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
         if (hc[1] != 0) return nullptr;   // 6: some partition's table filled up
         m = hc[0];
-        dense.resize((size_t)m * HW);
-        if (m > 0) QE_HIP(hipMemcpyAsync(dense.data(), d_out, dense.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (m > 0) {
+            dense = (unsigned long long *)ctx->pinned.alloc((size_t)m * HW * 8);
+            QE_HIP(hipMemcpyAsync(dense, d_out, (size_t)m * HW * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         QE_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         if (ctx->opts.profile) QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
