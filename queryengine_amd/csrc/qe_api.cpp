@@ -1736,7 +1736,11 @@ qe_result *run_groupby_hashed(qe_ctx *ctx, const qe_batch *batch, const Plan &pl
 // workgroup per partition aggregates its records in an LDS hash table and appends the used entries to the result.  Every pass
 // streams; no gather, no global atomic per row.  nullptr: a partition held more distinct keys than its table has buckets (the
 // caller takes another path and remembers).
-qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_ptr<Plan> &plan, const int32_t *agg_fns, int32_t nagg) {
+// `skewed` (optional) is set, and nullptr returned before the scatter pass, when one partition holds several times its share of
+// the records (a key that owns a large part of the rows): ONE workgroup aggregates a partition, so that workgroup would run
+// alone for most of the pass -- the dense-id path slices its partitions and does not mind.
+qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_ptr<Plan> &plan, const int32_t *agg_fns, int32_t nagg,
+                          bool *skewed = nullptr) {
     const CodegenOutput &cg = plan->cg;
     const int64_t n = batch->nrows;
     const int P = cg.nparts, HW = cg.hash_words;
@@ -1772,6 +1776,19 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
     }
     start[P] = m_records;
     if (m_records >= (1ull << 32)) return nullptr;   // record positions are 32-bit in the scatter pass
+    if (skewed) {
+        unsigned long long largest = 0;
+        for (int j = 0; j < P; j++) largest = std::max(largest, start[j + 1] - start[j]);
+        if (m_records > (1ull << 22) && largest > 3 * (m_records / (unsigned long long)P) + 65536) {
+            *skewed = true;
+            if (ctx->opts.profile) {   // (the bracket the caller reads must be closed)
+                QE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+                QE_HIP(hipStreamSynchronize(ctx->stream));
+                collect_time(ctx);
+            }
+            return nullptr;
+        }
+    }
     QE_HIP(hipMemcpyAsync(d_start, start.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     // the groups' entries come back through pinned staging (64 MB for 1 M groups: 1.5 ms instead of ~15 ms into pageable memory)
     unsigned long long *dense = nullptr;
@@ -2327,14 +2344,16 @@ int32_t qe_filter_groupby(qe_ctx *ctx, const qe_batch *batch, const qe_expr *fil
                 }
                 if (!hplan || !hplan->cg.hp) return nullptr;
                 qe_result *r = nullptr;
+                bool skewed = false;
                 try {
-                    r = run_groupby_hp(ctx, batch, hplan, agg_fns, nagg);
+                    r = run_groupby_hp(ctx, batch, hplan, agg_fns, nagg, &skewed);
                 } catch (const Error &e) {
                     // its record array (21 - 64 bytes per kept row) did not fit beside the batch: the dense-id path needs 4 + 16
                     // bytes per row -- this plan stays with that one (run_groupby_hp releases what it had allocated)
                     if (e.code != QE_ERR_OOM) throw;
                     plan->hp_failed = true;
                 }
+                if (skewed) plan->hp_failed = true;   // a property of the data: this plan stays with the forms that slice their work
                 if (r) {
                     plan->known_keys = r->count;
                     ctx->last_form = QE_FORM_GROUPBY_HASH_PARTITIONED;

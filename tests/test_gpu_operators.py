@@ -492,6 +492,34 @@ def test_group_by_numeric_keys_hashed_matches_oracle(case, oracle):
     ctx.close()
 
 
+def test_group_by_heavy_hitter_key_leaves_the_hash_partitioned_form(oracle):
+    """One key owns 60 % of 5 M rows, 50 000 more share the rest.  The plan's first execution finds many keys (the id build's first
+    table fills) and turns to the hash-partitioned form, whose count pass then shows one partition with most of the records: ONE
+    workgroup would aggregate it alone, so the form is given up for this plan (the dense-id path slices its partitions).  Same
+    groups as the oracle, in its order, on every execution."""
+    from queryengine_amd import ColumnExpression
+    from queryengine_amd import engine as E
+    rng = np.random.default_rng(5)
+    n = 5_000_000
+    k = np.where(rng.random(n) < 0.6, 0.0, np.floor(rng.random(n) * 50_000.0) + 1.0)
+    v = np.round(rng.normal(0, 100, n))
+    cols = [Column(D, k), Column(D, v)]
+    K, V = ColumnExpression("k", 0, D), ColumnExpression("v", 1, D)
+    aggs = [oracle.SUM, oracle.COUNT, oracle.MAX]
+    want = oracle.filter_groupby(cols, None, [K], [V, V, V], aggs, oracle.BYTECODE_COMPILER)
+    ctx = E.Context(device=0)
+    batch = E.DeviceBatch.from_columns(ctx, cols)
+    for rep in range(3):
+        res = E.filter_groupby(ctx, batch, None, [ctx.compile(K)], [ctx.compile(V), ctx.compile(V), ctx.compile(V)], aggs)
+        cs = res.to_columns()
+        got = [[c.value(i) for c in cs] for i in range(res.count)]
+        res.free()
+        assert ctx.last_form == N.FORM_GROUPBY_HASHED
+        _rows_equal(got, want, 1, aggs, oracle)
+    batch.free()
+    ctx.close()
+
+
 def test_tripdata_query_shape_group_by_double_column(gpu_ctx):
     """Tripdata.kt:27-31: SELECT passenger_count, MIN(fare_amount), MAX(fare_amount) FROM tripdata -- grouping by a DOUBLE
     column, through query() and the planner (implicit GROUP BY, RewriteAggregates.kt:21-47)."""
