@@ -19,7 +19,7 @@ sub(os.path.join(ROOT, 'DESIGN.md'), '| cfg 2, 5 % — headline | ring, wide geo
 | cfg 2, 1 % | local | {f('cfg2_sel001',0)} | 1.81–2.11 | 11.9 | {f('cfg2_sel001',1)} (0.70–0.82) | 2.02–2.07, 0.72 |
 | cfg 2, 10 % | ring | {f('cfg2_sel010',0)} | 3.86–4.43 | 25.8 | {f('cfg2_sel010',1)} (0.73–0.83) | 4.16, 0.77 |
 | cfg 2, 50 % | dense | {f('cfg2_sel050',0)} | 4.96–5.30 | 32.5 | {f('cfg2_sel050',1)} (0.77–0.82) | 5.20–5.27, 0.77 |
-| cfg 2, 100 % | dense | {f('cfg2_sel100',0)} | 6.02–6.52 | 40.1 | {f('cfg2_sel100',1)} (0.77–0.83) | 6.23–6.45, 0.78 |
+| cfg 2, 100 % | dense | {f('cfg2_sel100',0)} | 6.01–6.52 | 40.1 | {f('cfg2_sel100',1)} (0.77–0.83) | 6.23–6.45, 0.78 |
 | cfg 3 (Q6-shaped predicate) | local + stage-0 prefetch | **{f('cfg3',0)}** | 1.72–1.89 | 10.57 | **{f('cfg3',1)}** (0.70–0.77) | 2.01–2.14, 0.61–0.65 |
 | cfg 4 (dictionary equality) | local | **{f('cfg4',0,3)}** | 0.65–0.69 | 4.17 | **{f('cfg4',1)}** (0.75–0.80) | 0.79, 0.66 |
 
@@ -27,7 +27,7 @@ sub(os.path.join(ROOT, 'DESIGN.md'), '| cfg 2, 5 % — headline | ring, wide geo
 sub(os.path.join(ROOT, 'BASELINE.md'), '| cfg 2, 5 % — headline | ring |', 'The local form (DESIGN.md §3.1c) is the fused kernel for plans that keep', f'''| cfg 2, 5 % — headline | ring | {f('cfg2',0)} (3.11–3.54) | 19.96 → {f('cfg2',1)} (0.71–0.80) | 3.03–3.50 |
 | cfg 2 written `c < 0.5 AND a < 100` (`--workload config2_swapped`) | ring, conjuncts ordered from measured pass rates | {f('cfg2_swapped',0)} (3.00–3.51) | 19.96 → {f('cfg2_swapped',1)} (0.71–0.83) | ≈ 24 GB moved as written |
 | cfg 2 with ~1 % NULLs in every input (`--null-pct 1`; 25.16 GB algorithmic) | ring | {f('cfg2_null',0)} (3.54–4.09) | 22.3 → {f('cfg2_null',1)} (0.69–0.77) | 4.47 |
-| cfg 2, 1 % / 10 % / 50 % / 100 % | local / ring / dense / dense | {f('cfg2_sel001',0)} / {f('cfg2_sel010',0)} / {f('cfg2_sel050',0)} / {f('cfg2_sel100',0)} (fastest box: 1.81 / 3.86 / 4.96 / 6.02, slowest: 2.11 / 4.43 / 5.30 / 6.52) | 11.9 → {f('cfg2_sel001',1)} / 25.8 → {f('cfg2_sel010',1)} / 32.5 → {f('cfg2_sel050',1)} / 40.1 → {f('cfg2_sel100',1)} | 2.02 / 4.16 / 5.20 / 6.23–6.45 |
+| cfg 2, 1 % / 10 % / 50 % / 100 % | local / ring / dense / dense | {f('cfg2_sel001',0)} / {f('cfg2_sel010',0)} / {f('cfg2_sel050',0)} / {f('cfg2_sel100',0)} (fastest box: 1.81 / 3.86 / 4.96 / 6.01, slowest: 2.11 / 4.43 / 5.30 / 6.52) | 11.9 → {f('cfg2_sel001',1)} / 25.8 → {f('cfg2_sel010',1)} / 32.5 → {f('cfg2_sel050',1)} / 40.1 → {f('cfg2_sel100',1)} | 2.02 / 4.16 / 5.20 / 6.23–6.45 |
 | cfg 3 | local + stage-0 prefetch | {f('cfg3',0)} (1.72–1.89) | 10.57 → {f('cfg3',1)} (0.70–0.77) | 2.01–2.14 (0.61–0.65) |
 | cfg 4 | local | {f('cfg4',0,3)} (0.65–0.69) | 4.17 → {f('cfg4',1)} (0.75–0.80) | 0.79 (0.66) |
 
