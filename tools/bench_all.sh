@@ -4,6 +4,8 @@
 OUT=gpurun_out/bench_all.jsonl; : > $OUT
 run() { timeout -k 10 240 python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" >> $OUT 2>> gpurun_out/bench_all.err || echo "{\"failed\": \"$*\"}" >> $OUT; }
 run --workload config2
+run --workload config2_swapped
+run --workload config2 --null-pct 1
 run --workload config2 --selectivity 0.01
 run --workload config2 --selectivity 0.10
 run --workload config2 --selectivity 0.50
@@ -19,6 +21,7 @@ for line in open("gpurun_out/bench_all.jsonl"):
     if "failed" in j: print("FAILED", j); continue
     r = j["roofline"]
     print(f'{j["config"]["workload"][:70]:70s} {j["config"]["exec_mode"]:8s} rows {j["config"]["rows_per_gpu"]:>11d} sel {j["config"]["selected_rows_total"]/j["config"]["rows_total"]:.4f} '
-          f'step {j["ms_per_step"]:.3f} ms kernel {r["kernel_ms"]:.3f} ms {r["achieved"]:.0f} GB/s frac {r["frac"]:.3f} rows/s {j["value"]:.3e}')
+          f'step {j["ms_per_step"]:.3f} ms kernel {r["kernel_ms"]:.3f} ms {r["achieved"]:.0f} GB/s frac {r["frac"]:.3f} frac_moved {r.get("frac_moved") or 0:.3f} '
+          f'rows/s {j["value"]:.3e} {r["kernel"]}')
 PY
 timeout -k 10 120 python tools/bench_q6.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_q6.txt
