@@ -1566,6 +1566,81 @@ qe_result *run_groupby_ids(qe_ctx *ctx, const qe_batch *batch, const Plan &plan,
     return res.release();
 }
 
+// The same on the device, for results of many groups (1 M groups cost the host ~70 ms and crossed the link twice): the entries are
+// ordered by first row (their keys = the first rows, a stable LSD radix sort over as many 4-bit digits as the batch's row ids
+// have), then one kernel writes every result column -- key values, finished accumulators, validity bitmaps -- in that order.  The
+// host only learns which columns hold a NULL anywhere (a column without one carries no bitmap, as the host path decides).
+qe_result *finish_hashed_groups_on_device(qe_ctx *ctx, const CodegenOutput &cg, const unsigned long long *d_entries, int64_t m, int64_t nrows,
+                                          const int32_t *agg_fns, int32_t nagg) {
+    const int W = cg.hash_words, NK = (int)cg.keys.size();
+    std::vector<void *> temps;
+    struct GT { qe_ctx *c; std::vector<void *> *t; ~GT() { for (void *q : *t) c->pool.release(q); } } gt{ctx, &temps};
+    auto talloc = [&](size_t bytes) { void *q = ctx->pool.alloc(std::max<size_t>(bytes, 16)); temps.push_back(q); return q; };
+    unsigned long long *keys[2] = {(unsigned long long *)talloc((size_t)m * 8), (unsigned long long *)talloc((size_t)m * 8)};
+    uint32_t *rows[2] = {(uint32_t *)talloc((size_t)m * 4), (uint32_t *)talloc((size_t)m * 4)};
+    uint32_t *hist = (uint32_t *)talloc((size_t)16 * (size_t)((m + 1023) / 1024) * 4);
+    launch_group_sort_keys(ctx->stream, d_entries, W, 2 + NK, m, keys[0], rows[0]);
+    int bits = 1;
+    while (bits < 62 && (1ll << bits) < nrows) bits++;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 4) {
+        launch_radix_pass(ctx->stream, keys[cur], rows[cur], nullptr, m, shift, hist, keys[1 - cur], rows[1 - cur]);
+        cur = 1 - cur;
+    }
+    std::unique_ptr<qe_result, std::function<void(qe_result *)>> res(new qe_result(), [ctx](qe_result *r) { free_result(ctx, r); });
+    res->count = m;
+    res->capacity = m;
+    const size_t words = (size_t)std::max<int64_t>(1, (m + 63) / 64);
+    GroupFinishArgs a{};
+    a.entries = d_entries;
+    a.rows = rows[cur];
+    a.m = m;
+    a.words = W;
+    a.nkeys = NK;
+    a.nagg = nagg;
+    unsigned int *d_flags = (unsigned int *)talloc(64);
+    QE_HIP(hipMemsetAsync(d_flags, 0, 64, ctx->stream));
+    a.flags = d_flags;
+    for (int k = 0; k < NK; k++) {
+        OutColumn oc;
+        oc.type = cg.keys[k].type;
+        oc.dict = cg.keys[k].dict;
+        oc.dict_handle.d = oc.dict;
+        const size_t bytes = oc.type == QE_BOOLEAN ? words * 8 : (oc.type == QE_DOUBLE || oc.type == QE_INT64) ? (size_t)m * 8 : (size_t)m * 4;
+        oc.data = ctx->pool.alloc(std::max<size_t>(bytes, 16));
+        oc.validity = (uint64_t *)ctx->pool.alloc(words * 8);
+        res->cols.push_back(oc);
+        a.key_type[k] = oc.type;
+        a.key_data[k] = oc.data;
+        a.key_valid[k] = (unsigned long long *)oc.validity;
+    }
+    for (int i = 0; i < nagg; i++) {
+        OutColumn oc;
+        oc.type = QE_DOUBLE;
+        oc.data = ctx->pool.alloc(std::max<size_t>((size_t)m * 8, 16));
+        oc.validity = (uint64_t *)ctx->pool.alloc(words * 8);
+        res->cols.push_back(oc);
+        a.agg_fn[i] = agg_fns[i];
+        a.cnt_src[i] = cg.cnt_src[(size_t)i];
+        a.agg_data[i] = (double *)oc.data;
+        a.agg_valid[i] = (unsigned long long *)oc.validity;
+    }
+    launch_group_finish(ctx->stream, a);
+    unsigned int flags[16] = {};
+    QE_HIP(hipMemcpyAsync(flags, d_flags, 64, hipMemcpyDeviceToHost, ctx->stream));
+    QE_HIP(hipGetLastError());
+    QE_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < NK + nagg; c++) {   // a column without a NULL carries no bitmap
+        OutColumn &oc = res->cols[(size_t)c];
+        oc.nullable = flags[c < NK ? c : 4 + (c - NK)] != 0;
+        if (!oc.nullable) {
+            ctx->pool.release(oc.validity);
+            oc.validity = nullptr;
+        }
+    }
+    return res.release();
+}
+
 // The groups of a hashed GROUP BY, finished on the host: `dense` holds m entries of cg.hash_words words {state, null bits, key
 // words.., first row, (count, acc)..}.  Insertion order = ascending first row (LinkedHashMap, GroupByAggregationOperator.kt:22);
 // accumulators finish as Accumulators.kt:26-107 says.
@@ -1837,6 +1912,9 @@ qe_result *run_groupby_hp(qe_ctx *ctx, const qe_batch *batch, const std::shared_
         const unsigned int *hc = (const unsigned int *)ctx->h_ctrl;
         if (hc[1] != 0) return nullptr;   // 6: some partition's table filled up
         m = hc[0];
+        static const int64_t device_finish_from = std::getenv("QE_GROUPS_ON_DEVICE_FROM") ? std::atoll(std::getenv("QE_GROUPS_ON_DEVICE_FROM")) : 4096;
+        if (m >= ((ctx->opts.tuning[5] & 67108864) ? 1 : device_finish_from) && (int)cg.keys.size() <= 4 && nagg <= 8)   // (debug bit 67108864: always)
+            return finish_hashed_groups_on_device(ctx, cg, d_out, m, batch->nrows, agg_fns, nagg);
         if (m > 0) {
             dense = (unsigned long long *)ctx->pinned.alloc((size_t)m * HW * 8);
             QE_HIP(hipMemcpyAsync(dense, d_out, (size_t)m * HW * 8, hipMemcpyDeviceToHost, ctx->stream));

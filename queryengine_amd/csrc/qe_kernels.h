@@ -33,6 +33,26 @@ void launch_ht_init(hipStream_t s, unsigned long long *tab, int64_t nentries, co
 void launch_ht_collect(hipStream_t s, const unsigned long long *tab, int64_t nentries, int words, unsigned long long *dense,
                        unsigned int *counter);
 
+// ---- groups of a hashed GROUP BY finished on the device (qe_kernels.hip) ----
+// entries: m x `words` u64 {state, null bits of the keys, key words.., first row, (count, acc) per aggregate}
+// sort keys: keys[i] = first row of entry i, rows[i] = i; after the radix passes rows[] lists the entries in insertion order
+void launch_group_sort_keys(hipStream_t s, const unsigned long long *entries, int words, int first_row_word, int64_t m,
+                            unsigned long long *keys, uint32_t *rows);
+struct GroupFinishArgs {
+    const unsigned long long *entries;
+    const unsigned int *rows;        // entry of result row j
+    long long m;
+    int words, nkeys, nagg;
+    int key_type[4];                 // QE_* of the key columns
+    void *key_data[4];               // DOUBLE / INT64: u64[m]; INT32 / STRING: i32[m]; BOOLEAN: bitmap words
+    unsigned long long *key_valid[4];
+    int agg_fn[8], cnt_src[8];       // QE_AGG_*, and which aggregate's counter says whether aggregate i saw a value
+    double *agg_data[8];
+    unsigned long long *agg_valid[8];
+    unsigned int *flags;             // [k] = 1: some group has a NULL in key k; [4 + i]: aggregate i is NULL somewhere
+};
+void launch_group_finish(hipStream_t s, const GroupFinishArgs &a);
+
 // ---- ORDER BY (qe_sort.hip) ----
 // keys[i] = order-preserving u64 image of row i of the key column (0 under a NULL), rows[i] = i
 struct SortKeyArgs {

@@ -339,4 +339,68 @@ void launch_ht_collect(hipStream_t s, const unsigned long long *tab, int64_t nen
                        words, (u64 *)dense, counter);
 }
 
+// ---- groups of a hashed GROUP BY finished on the device: insertion order = ascending first row (LinkedHashMap,
+// GroupByAggregationOperator.kt:22), accumulators finished as Accumulators.kt:26-107 says -- what finish_hashed_groups does on
+// the host, for results of many groups (1 M groups: ~70 ms of host work and two trips over the link otherwise) -----------------
+__global__ void __launch_bounds__(256) group_sort_keys_kernel(const u64 *entries, int words, int first_row_word, i64 m, u64 *keys, u32 *rows) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        keys[i] = entries[i * words + first_row_word];
+        rows[i] = (u32)i;
+    }
+}
+void launch_group_sort_keys(hipStream_t s, const unsigned long long *entries, int words, int first_row_word, int64_t m,
+                            unsigned long long *keys, uint32_t *rows) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(group_sort_keys_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, (const u64 *)entries, words, first_row_word,
+                       (i64)m, (u64 *)keys, (u32 *)rows);
+}
+// thread j finishes result row j (64 consecutive rows per wave: one bitmap word per ballot)
+__global__ void __launch_bounds__(256) group_finish_kernel(const GroupFinishArgs a) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j < a.m;
+    const int lane = threadIdx.x & 63;
+    const u64 *e = a.entries + (live ? (i64)a.rows[j] : 0) * a.words;
+    const u64 knull = live ? e[1] : 0ull;
+    for (int k = 0; k < a.nkeys; ++k) {
+        const bool null = ((knull >> k) & 1ull) != 0ull;
+        const u64 kw = live && !null ? e[2 + k] : 0ull;
+        const int t = a.key_type[k];
+        if (t == QE_DOUBLE || t == QE_INT64) { if (live) ((u64 *)a.key_data[k])[j] = kw; }
+        else if (t == QE_BOOLEAN) {
+            const u64 bits = __ballot(live && kw != 0ull);
+            if (lane == 0 && live) ((u64 *)a.key_data[k])[j >> 6] = bits;
+        } else { if (live) ((int *)a.key_data[k])[j] = (int)(i64)kw; }
+        const u64 vb = __ballot(live && !null);
+        if (lane == 0 && live) a.key_valid[k][j >> 6] = vb;
+        if (live && null) a.flags[k] = 1u;
+    }
+    const u64 *acc = e + 2 + a.nkeys;   // {first row, (count, acc)..}
+    for (int i = 0; i < a.nagg; ++i) {
+        const u64 cnt = live ? acc[1 + 2 * a.cnt_src[i]] : 0ull;
+        const u64 raw = live ? acc[2 + 2 * i] : 0ull;
+        double v = 0.0;
+        bool ok = true;
+        switch (a.agg_fn[i]) {
+        case QE_AGG_COUNT: v = (double)cnt; break;                                  // Accumulators.kt:26-36
+        case QE_AGG_SUM: v = __builtin_bit_cast(double, raw); ok = cnt != 0ull; break;   // :47-53 empty => null
+        case QE_AGG_AVG: v = __builtin_bit_cast(double, raw); ok = cnt != 0ull; if (ok) v /= (double)cnt; break;
+        default: {                                                                          // MIN / MAX: undo the ordered key
+            const i64 key = (i64)raw;
+            v = __builtin_bit_cast(double, key ^ ((key >> 63) & 0x7fffffffffffffffll));
+            ok = cnt != 0ull;
+        }
+        }
+        if (!ok) v = 0.0;
+        if (live) a.agg_data[i][j] = v;
+        const u64 vb = __ballot(live && ok);
+        if (lane == 0 && live) a.agg_valid[i][j >> 6] = vb;
+        if (live && !ok) a.flags[4 + i] = 1u;
+    }
+}
+void launch_group_finish(hipStream_t s, const GroupFinishArgs &a) {
+    if (a.m <= 0) return;
+    hipLaunchKernelGGL(group_finish_kernel, dim3((unsigned)((a.m + 255) / 256)), dim3(256), 0, s, a);
+}
+
 }  // namespace qe
